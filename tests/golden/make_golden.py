@@ -1,0 +1,300 @@
+#!/usr/bin/env python3
+"""Mint the golden fixtures under tests/golden/ from the REAL reference.
+
+Run in the build container only (needs /root/reference, which never travels):
+
+    python tests/golden/make_golden.py            # all three parts
+
+What it does
+  tier_a   imports the reference's CrossModalTransformer / DeepTruthClassifier with
+           `transformers` masked (the reference's own "transformers is
+           optional" branch, so no name-based from_pretrained loader is reached),
+           loads oracle.tier_a.seeded_params(seed) into them, runs eval-mode forward,
+           CE loss, backward, clip_grad_norm_(5.0) and torch.optim.AdamW for 3 steps
+           (dropout p=0) at B in {2,4,32}; asserts the oracle restatement agrees
+           element-for-element, and stores the reference's outputs (full for the small
+           tensors, per-tensor digests for grads/params) in tier_a_B*.npz.
+  metrics  runs the reference's forensic_metrics on known inputs -> metrics_kat.json.
+  tier_b   builds the locally installed third-party BertModel / CLIPVisionModelWithProjection
+           from local configs (2 layers, small vocab; no from_pretrained), loads
+           oracle.encoders_ref.seeded_weights, stores inputs + outputs in tier_b.npz and
+           records one full-depth (12-layer) oracle-vs-third-party max-abs-err.
+
+Fixtures are data only (inputs, expected outputs, digests); weights are regenerated
+from the seed by oracle.* on both sides, with a checksum stored to catch drift.
+"""
+from __future__ import annotations
+
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parents[1]
+REF = Path("/root/reference")
+sys.path.insert(0, str(REPO))
+
+PARAM_SEED = 1234
+BATCH_SEEDS = {2: 7, 4: 11, 32: 13}
+
+
+def digest(t: torch.Tensor) -> dict:
+    f = t.detach().double().flatten()
+    n = f.numel()
+    stride = max(1, n // 16)
+    return {"norm": np.float64(f.norm().item()), "sum": np.float64(f.sum().item()),
+            "head": f[:16].float().numpy(), "strided": f[::stride][:16].float().numpy()}
+
+
+def put_digest(store: dict, prefix: str, t: torch.Tensor):
+    for k, v in digest(t).items():
+        store[f"{prefix}/{k}"] = np.asarray(v)
+
+
+# ---------------------------------------------------------------------------
+def tier_a():
+    sys.modules["transformers"] = None
+    os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, str(REF))
+    os.chdir(REF)
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from src.models.fusion.cross_modal_transformer import CrossModalTransformer
+    from src.models.fusion.deep_truth_classifier import DeepTruthClassifier
+    from oracle import tier_a as O
+
+    fus_sd, clf_sd = O.seeded_params(PARAM_SEED)
+    checksum = float(sum(v.double().sum() for v in list(fus_sd.values()) + list(clf_sd.values())))
+
+    for B, bseed in BATCH_SEEDS.items():
+        torch.manual_seed(0)
+        fusion = CrossModalTransformer("configs/model_configs/fusion.yaml").to("cpu")
+        clf = DeepTruthClassifier("configs/model_configs/classifier.yaml").to("cpu")
+        assert list(fusion.state_dict().keys()) == list(fus_sd.keys())
+        assert list(clf.state_dict().keys()) == list(clf_sd.keys())
+        fusion.load_state_dict(fus_sd)
+        clf.load_state_dict(clf_sd)
+        for m in list(fusion.modules()) + list(clf.modules()):
+            if isinstance(m, nn.Dropout):
+                m.p = 0.0
+        batch = O.seeded_batch(bseed, B)
+        feats = {k: batch[k] for k in ("text_features", "audio_features", "visual_features",
+                                       "temporal_features", "gnn_feat")}
+        store = {"param_seed": np.int64(PARAM_SEED), "batch_seed": np.int64(bseed),
+                 "param_checksum": np.float64(checksum)}
+        for k, v in batch.items():
+            store[f"in/{k}"] = v.numpy()
+
+        # ---- eval forward (reference) vs oracle
+        fusion.eval(); clf.eval()
+        with torch.no_grad():
+            fo = fusion(feats)
+            co = clf(fo["fused"], batch["aux"])
+        oo = O.forward_batch(fus_sd, clf_sd, batch, train=False)
+        for name, r, o in (("fused", fo["fused"], oo["fused"]), ("fusion_logits", fo["logits"], oo["fusion_logits"]),
+                           ("logits", co["logits"], oo["logits"]), ("probs", co["probs"], oo["probs"])):
+            err = (r - o).abs().max().item()
+            assert err <= 1e-6, (name, err)
+            store[f"out/{name}"] = r.numpy()
+        for k in ("emotion_intensity", "semantic_conflict", "temporal_delay"):
+            assert (fo["forensic"][k] - oo["forensic"][k]).abs().max().item() <= 1e-7
+            store[f"out/forensic/{k}"] = fo["forensic"][k].numpy()
+        store["out/temperature"] = co["temperature"].detach().numpy()
+
+        # ---- 3 train steps (reference torch.optim.AdamW + clip_grad_norm_) vs oracle
+        fusion.train(); clf.train()
+        params = list(fusion.parameters()) + list(clf.parameters())
+        optim = torch.optim.AdamW(params, lr=2e-4, weight_decay=1e-4)
+        of = {k: v.clone() for k, v in fus_sd.items()}
+        oc = {k: v.clone() for k, v in clf_sd.items()}
+        ostate = O.AdamWState()
+        for step in (1, 2, 3):
+            fo = fusion(feats)
+            co = clf(fo["fused"], batch["aux"])
+            loss = F.cross_entropy(co["logits"], batch["label"])
+            optim.zero_grad(set_to_none=True)
+            loss.backward()
+            if step == 1:
+                grads_ref = {("fusion." + k): (p.grad.clone() if p.grad is not None else None)
+                             for k, p in fusion.named_parameters()}
+                grads_ref.update({("clf." + k): (p.grad.clone() if p.grad is not None else None)
+                                  for k, p in clf.named_parameters()})
+            total = nn.utils.clip_grad_norm_(params, max_norm=5.0)
+            optim.step()
+            # oracle step
+            if step == 1:
+                _, oloss, gf, gc = O.loss_and_grads(of, oc, batch, train=False)
+                for k, g in {**{"fusion." + k: g for k, g in gf.items()},
+                             **{"clf." + k: g for k, g in gc.items()}}.items():
+                    r = grads_ref[k]
+                    assert (g is None) == (r is None), k
+                    if g is not None:
+                        err = (g - r).abs().max().item()
+                        assert err <= 2e-6 * max(1.0, r.abs().max().item()), (k, err)
+            oout, oloss, ototal = O.train_step(of, oc, batch, ostate, grad_clip=5.0, train=False)
+            assert abs(oloss - loss.item()) <= 1e-6, (oloss, loss.item())
+            assert abs(ototal - total.item()) <= 1e-5 * max(1.0, total.item())
+            store[f"step{step}/loss"] = np.float64(loss.item())
+            store[f"step{step}/grad_norm"] = np.float64(total.item())
+            store[f"step{step}/logits"] = co["logits"].detach().numpy()
+            if step == 1:
+                nograd = []
+                for k, g in grads_ref.items():
+                    if g is None:
+                        nograd.append(k)
+                    else:
+                        put_digest(store, f"grad/{k}", g)
+                store["nograd_keys"] = np.array(json.dumps(nograd))
+            if step in (1, 3):
+                worst = 0.0
+                for k, p in list(("fusion." + k, p) for k, p in fusion.named_parameters()) + \
+                        list(("clf." + k, p) for k, p in clf.named_parameters()):
+                    o = (of if k.startswith("fusion.") else oc)[k.split(".", 1)[1]]
+                    worst = max(worst, (p.detach() - o).abs().max().item())
+                    put_digest(store, f"param_step{step}/{k}", p.detach())
+                assert worst <= 2e-6, worst
+        np.savez_compressed(HERE / f"tier_a_B{B}.npz", **store)
+        print(f"tier_a B={B}: ok  loss={store['step1/loss']:.6f} gnorm={store['step1/grad_norm']:.6f}")
+
+
+# ---------------------------------------------------------------------------
+def metrics():
+    sys.modules["transformers"] = None
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, str(REF))
+    from src.training.metrics import forensic_metrics as RM
+    from oracle import metrics_ref as OM
+
+    rng = np.random.default_rng(5)
+    cases = []
+
+    def add(name, y, p, forensic=None, include_cm=False):
+        r = RM.aggregate_epoch_metrics(np.array(y), np.array(p), forensic=forensic and
+                                       {k: np.array(v) for k, v in forensic.items()},
+                                       threshold=0.5, include_cm=include_cm)
+        o = OM.aggregate_epoch_metrics(np.array(y), np.array(p), forensic=forensic and
+                                       {k: np.array(v) for k, v in forensic.items()},
+                                       threshold=0.5, include_cm=include_cm)
+        assert set(r) == set(o), (name, set(r) ^ set(o))
+        for k in r:
+            assert abs(r[k] - o[k]) <= 1e-12, (name, k, r[k], o[k])
+        cases.append({"name": name, "y": list(map(int, y)), "p": list(map(float, p)),
+                      "forensic": forensic, "include_cm": include_cm,
+                      "expected": {k: float(v) for k, v in r.items()}})
+
+    add("sanity_check.py:35-36", [0, 1, 1, 0], [0.1, 0.9, 0.8, 0.2])
+    add("survey_8c", [0, 1, 1, 0, 1, 0], [.2, .7, .4, .6, .9, .1],
+        {"semantic_conflict": [.1, .5, .9, .3, .2, .4], "temporal_delay": [.2, .4, .6, .8, 1.0, 0.0],
+         "emotion_intensity": [.1, .2, .3, .4, .5, .6]}, include_cm=True)
+    add("single_class", [1, 1, 1], [0.2, 0.7, 0.9],
+        {"semantic_conflict": [1.0, 1.0, 0.9], "temporal_delay": [1.0, 1.0, 1.0], "emotion_intensity": [0, 0, 0]})
+    add("ties", [0, 1, 0, 1, 1, 0, 0, 1], [0.5, 0.5, 0.5, 0.7, 0.2, 0.2, 0.9, 0.9])
+    add("all_negative_pred", [0, 1, 0, 1], [0.1, 0.2, 0.3, 0.4],
+        {"semantic_conflict": [0, 0, 0, 0], "temporal_delay": [0, 0, 0, 0], "emotion_intensity": [1, 1, 1, 1]})
+    y = rng.integers(0, 2, 257)
+    p = np.round(rng.random(257), 2)          # many ties
+    add("random_257", y.tolist(), p.tolist(),
+        {"semantic_conflict": rng.random(257).tolist(), "temporal_delay": rng.random(257).tolist(),
+         "emotion_intensity": rng.random(257).tolist()}, include_cm=True)
+    # two-column score inputs (_to_prob_1 branches, forensic_metrics.py:35-56)
+    two = []
+    for name, s in (("probs2", [[0.8, 0.2], [0.3, 0.7], [0.4, 0.6], [0.9, 0.1]]),
+                    ("logits2", [[2.0, -1.0], [0.1, 0.3], [-3.0, 1.0], [0.5, 0.2]])):
+        r = RM.compute_classification_metrics(np.array([0, 1, 1, 0]), np.array(s))
+        o = OM.compute_classification_metrics(np.array([0, 1, 1, 0]), np.array(s))
+        assert all(abs(r[k] - o[k]) <= 1e-12 for k in r)
+        two.append({"name": name, "y": [0, 1, 1, 0], "score": s, "expected": {k: float(v) for k, v in r.items()}})
+    (HERE / "metrics_kat.json").write_text(json.dumps({"aggregate": cases, "two_column": two}, indent=1))
+    print(f"metrics: {len(cases)} + {len(two)} KATs ok")
+
+
+# ---------------------------------------------------------------------------
+def tier_b():
+    from transformers import BertConfig, BertModel, CLIPVisionConfig, CLIPVisionModelWithProjection
+    from oracle import encoders_ref as E
+
+    store = {}
+    torch.manual_seed(0)
+    # ---- text: 2-layer BERT, small vocab (fixture-sized); production geometry otherwise
+    VOC = 1000
+    for tag, layers, B, L, vocab, seed in (("bert2_L128", 2, 4, 128, VOC, 21), ("bert2_L512", 2, 2, 512, VOC, 22),
+                                           ("bert2_L40", 2, 3, 40, VOC, 23)):
+        w = E.seeded_weights(E.bert_shapes(layers=layers, vocab=vocab), seed)
+        m = BertModel(BertConfig(num_hidden_layers=layers, vocab_size=vocab), add_pooling_layer=False).eval()
+        missing = m.load_state_dict(w, strict=True)
+        ids, mask = E.synthetic_tokens(seed + 100, B, L, vocab=vocab, min_len=min(16, L))
+        with torch.no_grad():
+            ref = m(input_ids=ids, attention_mask=mask).last_hidden_state
+        ora = E.bert_last_hidden_state(w, ids, mask)
+        valid = mask.bool()
+        err = (ref - ora)[valid].abs().max().item()
+        assert err <= 2e-5, (tag, err)
+        feat = E.masked_meanpool_l2(ref, mask)          # text_blocks.py:82-101 applied to the third-party output
+        store[f"{tag}/ids"] = ids.numpy().astype(np.int64)
+        store[f"{tag}/mask"] = mask.numpy().astype(np.int64)
+        store[f"{tag}/features"] = feat.numpy()
+        store[f"{tag}/hidden_row0"] = ref[0].numpy()[: int(mask[0].sum())]
+        store[f"{tag}/meta"] = np.array(json.dumps({"layers": layers, "vocab": vocab, "weight_seed": seed,
+                                                    "checksum": float(sum(v.double().sum() for v in w.values()))}))
+        print(f"tier_b {tag}: oracle-vs-third-party hidden max-abs-err {err:.2e}")
+
+    # ---- visual: 2-layer CLIP ViT-B/32
+    for tag, layers, B, Fr, seed in (("vit2_F1", 2, 3, 1, 31), ("vit2_F4", 2, 2, 4, 32)):
+        w = E.seeded_weights(E.vit_shapes(layers=layers), seed)
+        m = CLIPVisionModelWithProjection(CLIPVisionConfig(num_hidden_layers=layers)).eval()
+        m.load_state_dict(w, strict=True)
+        frames = E.synthetic_frames(seed + 100, B, Fr)
+        with torch.no_grad():
+            out = m(pixel_values=frames.reshape(B * Fr, 3, 224, 224))
+        pooled_o = E.vit_pooled(w, frames.reshape(B * Fr, 3, 224, 224))
+        e_ref = out.image_embeds
+        e_ora = torch.nn.functional.linear(pooled_o, w["visual_projection.weight"])
+        err = (e_ref - e_ora).abs().max().item()
+        assert err <= 2e-5, (tag, err)
+        feat_ref = e_ref / (e_ref.norm(dim=-1, keepdim=True) + 1e-9)
+        feat_ref = feat_ref.view(B, Fr, -1)
+        feat_ref = feat_ref[:, 0] if Fr == 1 else E.field_mean_l2(feat_ref)
+        assert (feat_ref - E.visual_features(w, frames)).abs().max().item() <= 1e-5
+        # frames are big: store the generator seed, not the pixels
+        store[f"{tag}/features"] = feat_ref.numpy()
+        store[f"{tag}/image_embeds"] = e_ref.numpy()
+        store[f"{tag}/meta"] = np.array(json.dumps({"layers": layers, "weight_seed": seed, "frame_seed": seed + 100,
+                                                    "B": B, "F": Fr, "frames_checksum": float(frames.double().sum()),
+                                                    "checksum": float(sum(v.double().sum() for v in w.values()))}))
+        print(f"tier_b {tag}: oracle-vs-third-party embeds max-abs-err {err:.2e}")
+
+    # ---- one full-depth check, scalar result recorded
+    w = E.seeded_weights(E.bert_shapes(layers=12, vocab=VOC), 41)
+    m = BertModel(BertConfig(vocab_size=VOC), add_pooling_layer=False).eval()
+    m.load_state_dict(w, strict=True)
+    ids, mask = E.synthetic_tokens(141, 2, 128, vocab=VOC)
+    with torch.no_grad():
+        ref = E.masked_meanpool_l2(m(input_ids=ids, attention_mask=mask).last_hidden_state, mask)
+    e12 = (ref - E.text_features(w, ids, mask)).abs().max().item()
+    w = E.seeded_weights(E.vit_shapes(layers=12), 42)
+    m = CLIPVisionModelWithProjection(CLIPVisionConfig()).eval()
+    m.load_state_dict(w, strict=True)
+    fr = E.synthetic_frames(142, 2, 1)
+    with torch.no_grad():
+        e = m(pixel_values=fr[:, 0]).image_embeds
+    v12 = (e / (e.norm(dim=-1, keepdim=True) + 1e-9) - E.visual_features(w, fr)).abs().max().item()
+    store["full_depth/bert12_feature_err"] = np.float64(e12)
+    store["full_depth/vit12_feature_err"] = np.float64(v12)
+    assert e12 <= 1e-5 and v12 <= 1e-5, (e12, v12)
+    print(f"tier_b full depth: bert12 feature err {e12:.2e}, vit12 feature err {v12:.2e}")
+    np.savez_compressed(HERE / "tier_b.npz", **store)
+
+
+if __name__ == "__main__":
+    part = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if part == "all":
+        for p in ("tier_a", "metrics", "tier_b"):
+            subprocess.check_call([sys.executable, str(Path(__file__).resolve()), p], cwd=str(REPO))
+    else:
+        {"tier_a": tier_a, "metrics": metrics, "tier_b": tier_b}[part]()

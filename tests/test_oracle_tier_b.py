@@ -1,0 +1,43 @@
+"""CPU: the Tier-B encoder oracle reproduces the third-party outputs stored in tests/golden/tier_b.npz
+(BertModel / CLIPVisionModelWithProjection built from local configs with seeded weights)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import encoders_ref as E
+from tests.helpers import load_npz
+
+
+@pytest.mark.parametrize("tag", ["bert2_L128", "bert2_L512", "bert2_L40"])
+def test_text_features(tag):
+    z = load_npz("tier_b.npz")
+    meta = json.loads(str(z[f"{tag}/meta"]))
+    w = E.seeded_weights(E.bert_shapes(layers=meta["layers"], vocab=meta["vocab"]), meta["weight_seed"])
+    assert abs(float(sum(v.double().sum() for v in w.values())) - meta["checksum"]) < 1e-6
+    ids, mask = torch.from_numpy(z[f"{tag}/ids"]), torch.from_numpy(z[f"{tag}/mask"])
+    hid = E.bert_last_hidden_state(w, ids, mask)
+    n0 = int(mask[0].sum())
+    assert np.abs(hid[0, :n0].numpy() - z[f"{tag}/hidden_row0"]).max() <= 2e-5
+    assert np.abs(E.masked_meanpool_l2(hid, mask).numpy() - z[f"{tag}/features"]).max() <= 2e-6
+
+
+@pytest.mark.parametrize("tag", ["vit2_F1", "vit2_F4"])
+def test_visual_features(tag):
+    z = load_npz("tier_b.npz")
+    meta = json.loads(str(z[f"{tag}/meta"]))
+    w = E.seeded_weights(E.vit_shapes(layers=meta["layers"]), meta["weight_seed"])
+    frames = E.synthetic_frames(meta["frame_seed"], meta["B"], meta["F"])
+    assert abs(float(frames.double().sum()) - meta["frames_checksum"]) < 1e-6
+    assert np.abs(E.visual_features(w, frames).numpy() - z[f"{tag}/features"]).max() <= 2e-6
+
+
+def test_pooling_edge_cases():
+    """text_blocks.py:82-86,100: all-masked row -> denom clamp 1e-6 -> zero vector, no NaN."""
+    h = torch.randn(2, 5, 8)
+    m = torch.tensor([[1, 1, 0, 0, 0], [0, 0, 0, 0, 0]])
+    f = E.masked_meanpool_l2(h, m)
+    assert torch.isfinite(f).all() and f[1].abs().max() == 0
+    assert abs(f[0].norm().item() - 1.0) < 1e-5
+    assert torch.allclose(E.field_mean_l2(f[None, :1]), f[:1], atol=1e-6)
