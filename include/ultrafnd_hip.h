@@ -1,0 +1,179 @@
+/* ultrafnd_hip.h -- C ABI of libultrafnd_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the text+vision fusion train-step hot path of
+ * Nuralamsiddik16/Ultrafnd_git.  The reference has no FFI of its
+ * own (it is pure Python on torch CPU/MPS); each entry point below names the reference
+ * Python interface it replaces (file:line under the reference root).  INTEGRATION.md
+ * shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless it says host;
+ *   - row-major, fp32 unless a name says bf16 (bf16 = raw uint16 storage);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing
+ *     allocates, frees or synchronises (safe inside hipGraph capture);
+ *   - return 0 on success, a UFND_ERR_* code otherwise; ufnd_last_error() gives the text;
+ *   - buffers are caller-owned; nothing is retained across calls.
+ */
+#ifndef ULTRAFND_HIP_H
+#define ULTRAFND_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UFND_OK 0
+#define UFND_ERR_INVALID 1 /* bad argument: shape, alignment, null pointer */
+#define UFND_ERR_LAUNCH 2  /* HIP launch error */
+
+#define UFND_ABI_VERSION 1
+
+const char* ufnd_last_error(void);
+int ufnd_abi_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Device-resident step state (graph-replay safe: hyper-parameters and counters are read
+ * from memory, never baked into launches).  Host initialises it with hipMemcpy.
+ * ---------------------------------------------------------------------------------- */
+typedef struct ufnd_step_state {
+  uint64_t step;       /* optimizer steps taken so far (AdamW's t-1); ++ by ufnd_adamw_step */
+  uint64_t seed;       /* dropout key */
+  float lr;            /* current learning rate (StepLR writes it between epochs) */
+  float weight_decay;
+  float beta1, beta2, eps;
+  float max_norm;      /* clip_grad_norm_ max_norm; <= 0 disables clipping */
+  float grad_scale;    /* multiplied into every gradient before use (1/world for summed DP grads) */
+  float loss;          /* out: mean CE loss of the last ufnd_softmax_ce */
+  float grad_norm;     /* out: global L2 norm (after grad_scale, before clipping) */
+  float clip_coef;     /* out: min(1, max_norm / (grad_norm + 1e-6)) */
+  float bc1, bc2_sqrt; /* out: 1-beta1^t, sqrt(1-beta2^t) for the step being applied */
+  float reserved[3];
+} ufnd_step_state;
+
+/* ------------------------------------------------------------------------------------
+ * Tier A geometry (configs/model_configs/fusion.yaml:2-7, classifier.yaml:2-17)
+ * ---------------------------------------------------------------------------------- */
+typedef struct ufnd_dims {
+  int hidden;       /* 512; must be a multiple of 256 */
+  int text_dim;     /* 768 */
+  int audio_dim;    /* 128 */
+  int visual_dim;   /* 512 */
+  int temporal_dim; /* 256 */
+  int gnn_dim;      /* 128 */
+  int aux_dim;      /* 2 (0 = classifier without aux) */
+  int trees;        /* 6 */
+  int depth;        /* 4 (<= 6) */
+  int classes;      /* 2 (only 2 is supported) */
+  float fusion_dropout; /* 0.1 */
+  float clf_dropout;    /* 0.1 */
+  float node_dropout;   /* 0.3 */
+} ufnd_dims;
+
+/* Parameter (or gradient) pointer table.  The same struct type carries the gradients.
+ * Names follow the reference's state_dict.  Three groups must be
+ * CONTIGUOUS in memory because the kernels treat them as one stacked matrix:
+ *   qkv_w : rows [attn_tv.q, attn_ta.q, attn_tv.k, attn_tv.v, attn_vu.q,
+ *                 attn_ta.k, attn_ta.v, attn_vu.k, attn_vu.v] each (hidden x hidden)
+ *   qkv_b : the nine biases in the same order
+ *   gates : node.trees.{t}.gates.{k} for t-major, k-minor, each (hidden)
+ *   thresh: node.trees.{t}.thresh.{k}, same order, one float each
+ *   leaf  : node.trees.{t}.leaf_logits, t-major, each (2^depth x classes)
+ *   tau   : node.trees.{t}.tau, one float each
+ */
+typedef struct ufnd_fusion_params {
+  float *text_w, *text_b;         /* text_proj      (hidden x text_dim)   cross_modal_transformer.py:96 */
+  float *audio_w, *audio_b;       /* audio_proj                                                    :97 */
+  float *visual_w, *visual_b;     /* visual_proj                                                   :98 */
+  float *temporal_w, *temporal_b; /* temporal_proj                                                 :99 */
+  float *gnn_w, *gnn_b;           /* gnn_proj                                                      :102 */
+  float *qkv_w, *qkv_b;           /* stacked co-attention projections                              :31-33 */
+  float *ev0_w[3], *ev0_b[3];     /* attn_{tv,ta,vu}.evidence_proj.0 (hidden x 3), (hidden)        :34-38 */
+  float *ev2_w[3], *ev2_b[3];     /* attn_{tv,ta,vu}.evidence_proj.2 (1 x hidden), (1)                    */
+  float *fuse0_w, *fuse0_b;       /* fuse_mlp.0 (2*hidden x 16*hidden)                             :122 */
+  float *fuse3_w, *fuse3_b;       /* fuse_mlp.3 (hidden x 2*hidden)                                :125 */
+  float *cls_w, *cls_b;           /* classifier (2 x hidden) -- aux head, no grad under the trainer :130 */
+} ufnd_fusion_params;
+
+typedef struct ufnd_clf_params {
+  float *pre0_w, *pre0_b;     /* pre.0 (hidden x (hidden+aux_dim))   deep_truth_classifier.py:122 */
+  float *pre3_w, *pre3_b;     /* pre.3 (hidden x hidden)                                     :125 */
+  float *gates, *thresh;      /* NODE gates / thresholds                                     :44-45 */
+  float *leaf, *tau;          /* leaf logits, temperature tau per tree                       :41,49 */
+  float *bypass_w, *bypass_b; /* bypass (classes x hidden)                                   :137 */
+  float *temperature;         /* scalar                                                      :115 */
+} ufnd_clf_params;
+
+/* ------------------------------------------------------------------------------------
+ * Workspaces.  Sizes depend on the batch size only; the caller allocates `floats`
+ * fp32 elements (256-byte aligned) and passes the base pointer to every call of the
+ * same batch size.  Forward leaves its saved activations there for backward.
+ * ---------------------------------------------------------------------------------- */
+size_t ufnd_fusion_workspace_floats(const ufnd_dims* d, int B);
+size_t ufnd_clf_workspace_floats(const ufnd_dims* d, int B);
+
+/* ------------------------------------------------------------------------------------
+ * CrossModalTransformer.forward                 src/models/fusion/cross_modal_transformer.py:134-210
+ *   in : text (B,text_dim) audio (B,audio_dim) visual (B,visual_dim) temporal (B,temporal_dim)
+ *        gnn (B,gnn_dim); contiguous rows.  gnn must be given (the reference's fuse_mlp is
+ *        built for the 16*hidden concat and rejects a missing gnn_feat, :184-195).
+ *   out: fused (B,hidden) with row stride ld_fused (multiple of 4), logits (B,2) or NULL to
+ *        skip the aux head, forensic (3,B) = emotion_intensity, semantic_conflict, temporal_delay.
+ *   train != 0 applies dropout with the mask keyed by state->{seed,step}.
+ * ---------------------------------------------------------------------------------- */
+int ufnd_fusion_forward(const ufnd_dims* d, const ufnd_fusion_params* p, const float* text, const float* audio,
+                        const float* visual, const float* temporal, const float* gnn, int B, int train,
+                        float* workspace, float* fused, int ld_fused, float* logits, float* forensic,
+                        const ufnd_step_state* state, void* stream);
+
+/* autograd backward of the above (what loss.backward() runs, forensic_trainer.py:291).
+ *   d_fused (B,hidden) stride ld_dfused; d_logits (B,2) or NULL.  Writes EVERY gradient in
+ *   `g` that can receive one (cls_w/cls_b only when d_logits != NULL; overwritten, not
+ *   accumulated).  Inputs get no gradient (they are data). */
+int ufnd_fusion_backward(const ufnd_dims* d, const ufnd_fusion_params* p, const ufnd_fusion_params* g,
+                         const float* text, const float* audio, const float* visual, const float* temporal,
+                         const float* gnn, int B, int train, float* workspace, const float* d_fused,
+                         int ld_dfused, const float* d_logits, const ufnd_step_state* state, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * DeepTruthClassifier.forward                   src/models/fusion/deep_truth_classifier.py:148-171
+ *   fused (B,hidden) stride ld_fused; aux (B,aux_dim) or NULL when aux_dim == 0.
+ *   out: logits (B,2), probs (B,2) = softmax(logits / clamp(temperature,0.5,5)).
+ *   If `fused` already points at the workspace's input panel (ufnd_clf_input_panel) the
+ *   copy is skipped -- the fused train step lets the fusion write there directly.
+ * ---------------------------------------------------------------------------------- */
+float* ufnd_clf_input_panel(const ufnd_dims* d, float* clf_workspace, int B, int* ld);
+int ufnd_classifier_forward(const ufnd_dims* d, const ufnd_clf_params* p, const float* fused, int ld_fused,
+                            const float* aux, int B, int train, float* workspace, float* logits, float* probs,
+                            const ufnd_step_state* state, void* stream);
+/* backward for a gradient arriving at `logits` (the trainer's CE-on-logits loss; temperature
+ * and tau get no gradient, deep_truth_classifier.py:41,164-170).  d_fused (B,hidden) stride
+ * ld_dfused is written. */
+int ufnd_classifier_backward(const ufnd_dims* d, const ufnd_clf_params* p, const ufnd_clf_params* g, int B,
+                             int train, float* workspace, const float* d_logits, float* d_fused, int ld_dfused,
+                             const ufnd_step_state* state, void* stream);
+
+/* F.cross_entropy(logits, y), mean reduction, + its gradient (forensic_trainer.py:287).
+ * labels int64 (B).  loss_rows (B) or NULL; d_logits (B,2) = (softmax - onehot)/B or NULL.
+ * state->loss receives the mean (summed in a fixed order: bit-reproducible). */
+int ufnd_softmax_ce(const float* logits, const int64_t* labels, int B, float* loss_rows, float* d_logits,
+                    ufnd_step_state* state, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * clip_grad_norm_ + AdamW.step over a flat fp32 arena    forensic_trainer.py:292-298,176
+ *   grad/param/exp_avg/exp_avg_sq: n floats each (n % 4 == 0, 16-byte aligned).
+ *   ufnd_grad_norm : state->grad_norm = ||grad * grad_scale||_2, clip_coef, bias corrections
+ *                    for step t = state->step + 1.  partials: >= 1024 floats scratch.
+ *   ufnd_adamw_step: p *= 1 - lr*wd; m,v update with g = grad*grad_scale*clip_coef; p -= ...
+ *   ufnd_step_advance: state->step += 1 (once per optimizer step, after every arena is done).
+ * ---------------------------------------------------------------------------------- */
+int ufnd_grad_norm(const float* grad, size_t n, float* partials, ufnd_step_state* state, void* stream);
+int ufnd_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                    const ufnd_step_state* state, void* stream);
+int ufnd_step_advance(ufnd_step_state* state, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ULTRAFND_HIP_H */

@@ -1,0 +1,156 @@
+"""ctypes binding of libultrafnd_hip.so (the C ABI declared in include/ultrafnd_hip.h).
+
+There is NO CPU fallback: if the library is missing, or a call is made with tensors that do
+not live on a HIP device, this raises.  torch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+from typing import Optional
+
+import torch
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libultrafnd_hip.so"
+
+
+class UltrafndHipError(RuntimeError):
+    pass
+
+
+# ------------------------------------------------------------------ structs (mirror the header)
+class StepState(C.Structure):
+    _fields_ = [("step", C.c_uint64), ("seed", C.c_uint64), ("lr", C.c_float), ("weight_decay", C.c_float),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("max_norm", C.c_float),
+                ("grad_scale", C.c_float), ("loss", C.c_float), ("grad_norm", C.c_float), ("clip_coef", C.c_float),
+                ("bc1", C.c_float), ("bc2_sqrt", C.c_float), ("reserved", C.c_float * 3)]
+
+
+class Dims(C.Structure):
+    _fields_ = [("hidden", C.c_int), ("text_dim", C.c_int), ("audio_dim", C.c_int), ("visual_dim", C.c_int),
+                ("temporal_dim", C.c_int), ("gnn_dim", C.c_int), ("aux_dim", C.c_int), ("trees", C.c_int),
+                ("depth", C.c_int), ("classes", C.c_int), ("fusion_dropout", C.c_float), ("clf_dropout", C.c_float),
+                ("node_dropout", C.c_float)]
+
+
+_FP = C.c_void_p
+
+
+class FusionParams(C.Structure):
+    _fields_ = [(n, _FP) for n in ("text_w", "text_b", "audio_w", "audio_b", "visual_w", "visual_b", "temporal_w",
+                                   "temporal_b", "gnn_w", "gnn_b", "qkv_w", "qkv_b")] + \
+               [("ev0_w", _FP * 3), ("ev0_b", _FP * 3), ("ev2_w", _FP * 3), ("ev2_b", _FP * 3)] + \
+               [(n, _FP) for n in ("fuse0_w", "fuse0_b", "fuse3_w", "fuse3_b", "cls_w", "cls_b")]
+
+
+class ClfParams(C.Structure):
+    _fields_ = [(n, _FP) for n in ("pre0_w", "pre0_b", "pre3_w", "pre3_b", "gates", "thresh", "leaf", "tau",
+                                   "bypass_w", "bypass_b", "temperature")]
+
+
+STEP_STATE_BYTES = C.sizeof(StepState)
+
+_lib: Optional[C.CDLL] = None
+
+
+def _declare(lib: C.CDLL) -> None:
+    P, I, S = C.c_void_p, C.c_int, C.c_size_t
+    lib.ufnd_last_error.restype = C.c_char_p
+    lib.ufnd_abi_version.restype = I
+    lib.ufnd_fusion_workspace_floats.restype = S
+    lib.ufnd_fusion_workspace_floats.argtypes = [C.POINTER(Dims), I]
+    lib.ufnd_clf_workspace_floats.restype = S
+    lib.ufnd_clf_workspace_floats.argtypes = [C.POINTER(Dims), I]
+    lib.ufnd_clf_input_panel.restype = P
+    lib.ufnd_clf_input_panel.argtypes = [C.POINTER(Dims), P, I, C.POINTER(I)]
+    lib.ufnd_fusion_forward.argtypes = [C.POINTER(Dims), C.POINTER(FusionParams), P, P, P, P, P, I, I, P, P, I, P, P, P, P]
+    lib.ufnd_fusion_backward.argtypes = [C.POINTER(Dims), C.POINTER(FusionParams), C.POINTER(FusionParams),
+                                         P, P, P, P, P, I, I, P, P, I, P, P, P]
+    lib.ufnd_classifier_forward.argtypes = [C.POINTER(Dims), C.POINTER(ClfParams), P, I, P, I, I, P, P, P, P, P]
+    lib.ufnd_classifier_backward.argtypes = [C.POINTER(Dims), C.POINTER(ClfParams), C.POINTER(ClfParams), I, I, P, P, P,
+                                             I, P, P]
+    lib.ufnd_softmax_ce.argtypes = [P, P, I, P, P, P, P]
+    lib.ufnd_grad_norm.argtypes = [P, S, P, P, P]
+    lib.ufnd_adamw_step.argtypes = [P, P, P, P, S, P, P]
+    lib.ufnd_step_advance.argtypes = [P, P]
+    for name in ("ufnd_fusion_forward", "ufnd_fusion_backward", "ufnd_classifier_forward", "ufnd_classifier_backward",
+                 "ufnd_softmax_ce", "ufnd_grad_norm", "ufnd_adamw_step", "ufnd_step_advance"):
+        getattr(lib, name).restype = I
+    _declare_encoders(lib)
+
+
+def _declare_encoders(lib: C.CDLL) -> None:
+    """Tier-B entry points (declared separately so a header/library mismatch is reported by name)."""
+    P, I, S, F = C.c_void_p, C.c_int, C.c_size_t, C.c_float
+    if not hasattr(lib, "ufnd_gemm_bf16"):
+        return
+    lib.ufnd_gemm_bf16.argtypes = [P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]
+    lib.ufnd_gemm_bf16.restype = I
+    lib.ufnd_layernorm.argtypes = [P, P, P, P, P, I, I, F, P]
+    lib.ufnd_layernorm.restype = I
+    lib.ufnd_attention_bf16.argtypes = [P, P, P, I, I, I, I, P]
+    lib.ufnd_attention_bf16.restype = I
+    lib.ufnd_bert_embed.argtypes = [P, P, P, P, P, P, P, P, I, I, I, F, P]
+    lib.ufnd_bert_embed.restype = I
+    lib.ufnd_masked_meanpool_l2.argtypes = [P, P, P, I, I, I, P]
+    lib.ufnd_masked_meanpool_l2.restype = I
+    lib.ufnd_vit_patchify.argtypes = [P, P, I, I, I, P]
+    lib.ufnd_vit_patchify.restype = I
+    lib.ufnd_vit_assemble.argtypes = [P, P, P, P, P, P, P, I, I, I, F, P]
+    lib.ufnd_vit_assemble.restype = I
+    lib.ufnd_l2norm_frames.argtypes = [P, P, I, I, I, P]
+    lib.ufnd_l2norm_frames.restype = I
+    lib.ufnd_cast_bf16.argtypes = [P, P, S, P]
+    lib.ufnd_cast_bf16.restype = I
+
+
+def lib() -> C.CDLL:
+    """The loaded library; raises (never falls back) when it is not built."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise UltrafndHipError(
+                f"{LIB_PATH} is missing: run `python -m ultrafnd_git_amd.build` (hipcc, gfx950). "
+                "This package has no CPU fallback.")
+        l = C.CDLL(str(LIB_PATH))
+        _declare(l)
+        if l.ufnd_abi_version() != 1:
+            raise UltrafndHipError("libultrafnd_hip.so ABI version mismatch; rebuild")
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise UltrafndHipError(f"{what} failed (code {rc}): {lib().ufnd_last_error().decode()}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def require_hip(*tensors: Optional[torch.Tensor]) -> torch.device:
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if t.device.type != "cuda":
+            raise UltrafndHipError(
+                f"tensor on {t.device}: the fusion hot path runs on a HIP device only (no CPU fallback); "
+                "move the module and its inputs to 'cuda'")
+        dev = dev or t.device
+        if t.device != dev:
+            raise UltrafndHipError("all tensors of one call must live on the same device")
+    return dev
+
+
+def stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def f32c(t: torch.Tensor) -> torch.Tensor:
+    """fp32 + contiguous (no copy when already so)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()

@@ -1,0 +1,168 @@
+"""DeepTruthClassifier -- MI355X-native mirror of the reference's NODE-ensemble classifier
+(src/models/fusion/deep_truth_classifier.py:28-74,77-90,97-184).
+
+Same constructor / YAML keys / `forward(fused, aux) -> {"logits","probs","temperature"}` /
+`predict_proba` / `predict` / `state_dict` names and the same initialisation order.  The
+arithmetic (pre-MLP, 6 soft oblivious trees, bypass, temperature softmax) runs in
+libultrafnd_hip.so; there is no CPU path.  The offline explainability helpers
+(`feature_importance`, `explain_shap`, :189-272) are out of scope.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .arena import ArenaModule, Group, rehome
+from .config_utils import ConfigManager
+from .state import StepStateBuffer
+
+
+def _init_lin(m: nn.Linear):
+    nn.init.xavier_uniform_(m.weight)
+    if m.bias is not None:
+        nn.init.zeros_(m.bias)
+
+
+class _ObliviousTree(nn.Module):
+    """Parameter container of one soft oblivious tree (deep_truth_classifier.py:36-52)."""
+
+    def __init__(self, in_dim: int, num_classes: int = 2, depth: int = 4, tau: float = 10.0, dropout: float = 0.3):
+        super().__init__()
+        self.in_dim, self.depth, self.num_classes = in_dim, depth, num_classes
+        self.tau = nn.Parameter(torch.tensor(float(tau)), requires_grad=False)
+        self.gates = nn.ParameterList([nn.Parameter(torch.zeros(in_dim)) for _ in range(depth)])
+        self.thresh = nn.ParameterList([nn.Parameter(torch.zeros(1)) for _ in range(depth)])
+        self.num_leaves = 1 << depth
+        self.leaf_logits = nn.Parameter(torch.zeros(self.num_leaves, num_classes))
+        self.dropout = nn.Dropout(dropout)
+
+
+class NODEEnsemble(nn.Module):
+    def __init__(self, in_dim: int, num_classes: int = 2, num_trees: int = 6, depth: int = 4, tau: float = 10.0,
+                 dropout: float = 0.3):
+        super().__init__()
+        self.trees = nn.ModuleList([_ObliviousTree(in_dim, num_classes, depth=depth, tau=tau, dropout=dropout)
+                                    for _ in range(num_trees)])
+
+
+class DeepTruthClassifier(ArenaModule):
+    def __init__(self, config_path: str = "configs/model_configs/classifier.yaml"):
+        super().__init__()
+        cfg = ConfigManager().load_config(config_path)
+        self.hidden = int(cfg.get("hidden_dim", 512))
+        self.dropout = float(cfg.get("dropout", 0.3))
+        self.num_classes = int(cfg.get("num_classes", 2))
+        self.use_aux = bool(cfg.get("use_aux", True))
+        self.aux_dim = int(cfg.get("aux_dim", 2))
+        self.node_trees = int(cfg.get("node_trees", 6))
+        self.node_depth = int(cfg.get("node_depth", 4))
+        self.node_tau = float(cfg.get("node_tau", 10.0))
+        self.node_dropout = 0.3   # hard-coded in the reference (deep_truth_classifier.py:132)
+        self.temperature = nn.Parameter(torch.tensor(float(cfg.get("temperature", 1.0))), requires_grad=True)
+        in_dim = int(cfg.get("input_dim", self.hidden))
+        if in_dim != self.hidden:
+            raise ValueError("input_dim must equal hidden_dim (the fusion head's output width)")
+        if self.num_classes != 2:
+            raise ValueError("the HIP path implements the reference's binary head (num_classes=2)")
+        self.eff_aux = self.aux_dim if self.use_aux else 0
+        self.pre = nn.Sequential(nn.Linear(in_dim + self.eff_aux, self.hidden), nn.GELU(), nn.Dropout(self.dropout),
+                                 nn.Linear(self.hidden, self.hidden), nn.GELU(), nn.Dropout(self.dropout))
+        for m in self.pre:
+            if isinstance(m, nn.Linear):
+                _init_lin(m)
+        self.node = NODEEnsemble(self.hidden, self.num_classes, self.node_trees, self.node_depth, self.node_tau, self.node_dropout)
+        self.bypass = nn.Linear(self.hidden, self.num_classes)
+        _init_lin(self.bypass)
+        self._ws: Dict[Tuple[int, bool], torch.Tensor] = {}
+        self._ptab = self._gtab = None
+        self._rng: Optional[StepStateBuffer] = None
+        rehome([self], [""])
+
+    # ------------------------------------------------------------------ arena layout
+    def _arena_groups(self) -> Tuple[List[Group], List[Group]]:
+        H, T, D = self.hidden, self.node_trees, self.node_depth
+        pre = [("pre.0.weight", (H, H + self.eff_aux)), ("pre.0.bias", (H,)), ("pre.3.weight", (H, H)), ("pre.3.bias", (H,))]
+        gates = [(f"node.trees.{t}.gates.{k}", (H,)) for t in range(T) for k in range(D)]
+        thresh = [(f"node.trees.{t}.thresh.{k}", (1,)) for t in range(T) for k in range(D)]
+        leaf = [(f"node.trees.{t}.leaf_logits", (1 << D, 2)) for t in range(T)]
+        byp = [("bypass.weight", (2, H)), ("bypass.bias", (2,))]
+        tau = [(f"node.trees.{t}.tau", ()) for t in range(T)]
+        return [[p] for p in pre] + [gates, thresh, leaf] + [[b] for b in byp], [[("temperature", ())], tau]
+
+    def _on_rehome(self) -> None:
+        self._ptab = self._gtab = None
+        self._ws.clear()
+        self._rng = None
+
+    def dims(self) -> L.Dims:
+        d = L.Dims()
+        d.hidden, d.text_dim, d.audio_dim, d.visual_dim, d.temporal_dim, d.gnn_dim = self.hidden, 768, 128, 512, 256, 128
+        d.aux_dim, d.trees, d.depth, d.classes = self.eff_aux, self.node_trees, self.node_depth, 2
+        d.fusion_dropout, d.clf_dropout, d.node_dropout = 0.1, self.dropout, self.node_dropout
+        return d
+
+    def _table(self, getter, with_nograd: bool) -> L.ClfParams:
+        t = L.ClfParams()
+        t.pre0_w, t.pre0_b = getter("pre.0.weight").data_ptr(), getter("pre.0.bias").data_ptr()
+        t.pre3_w, t.pre3_b = getter("pre.3.weight").data_ptr(), getter("pre.3.bias").data_ptr()
+        t.gates = getter("node.trees.0.gates.0").data_ptr()
+        t.thresh = getter("node.trees.0.thresh.0").data_ptr()
+        t.leaf = getter("node.trees.0.leaf_logits").data_ptr()
+        t.bypass_w, t.bypass_b = getter("bypass.weight").data_ptr(), getter("bypass.bias").data_ptr()
+        if with_nograd:
+            t.tau = getter("node.trees.0.tau").data_ptr()
+            t.temperature = getter("temperature").data_ptr()
+        return t
+
+    def param_table(self) -> L.ClfParams:
+        if self._ptab is None:
+            self._ptab = self._table(self.aview, True)
+        return self._ptab
+
+    def grad_table(self) -> L.ClfParams:
+        if self._gtab is None:
+            self._gtab = self._table(self.gview, False)
+        return self._gtab
+
+    def workspace(self, B: int, train: bool) -> torch.Tensor:
+        key = (B, bool(train))
+        if key not in self._ws:
+            d = self.dims()
+            n = L.lib().ufnd_clf_workspace_floats(C.byref(d), B)
+            self._ws[key] = torch.empty(n, dtype=torch.float32, device=self._arena.device)
+        return self._ws[key]
+
+    def rng(self) -> StepStateBuffer:
+        if self._rng is None:
+            self._rng = StepStateBuffer(self._arena.device, seed=torch.initial_seed() + 0xC1F)
+        return self._rng
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, fused: torch.Tensor, aux: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        dev = self._arena.device
+        if dev.type != "cuda":
+            raise L.UltrafndHipError("DeepTruthClassifier runs on a HIP device only: call .to('cuda') "
+                                     "(there is no CPU fallback)")
+        fused = fused.to(dev, dtype=torch.float32)
+        if self.use_aux and aux is None:
+            raise RuntimeError(f"aux is required: pre.0 is built for {self.hidden}+{self.aux_dim} inputs "
+                               "(the reference's Linear fails the same way, deep_truth_classifier.py:142-146,162)")
+        aux = L.f32c(aux.to(dev)) if (self.use_aux and aux is not None) else None
+        from .functional import ClassifierFunction
+        needs_grad = torch.is_grad_enabled() and (fused.requires_grad or any(p.requires_grad for p in self.parameters()))
+        logits, probs = ClassifierFunction.apply(self, self.training, needs_grad, fused, aux,
+                                                 *[p for p in self.parameters() if p.requires_grad])
+        t = torch.clamp(self.temperature, min=0.5, max=5.0)
+        return {"logits": logits, "probs": probs, "temperature": t}
+
+    @torch.no_grad()
+    def predict_proba(self, fused: torch.Tensor, aux: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return self.forward(fused, aux)["probs"]
+
+    @torch.no_grad()
+    def predict(self, fused: torch.Tensor, aux: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return self.predict_proba(fused, aux).argmax(dim=-1)

@@ -1,0 +1,88 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels.  wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/ultrafnd_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+#define UFND_WAVE 64
+
+// ------------------------------------------------------------------ error plumbing (host)
+void ufnd_set_error(const char* fmt, ...);
+#define UFND_REQUIRE(cond, ...)                      \
+  do {                                               \
+    if (!(cond)) {                                   \
+      ufnd_set_error(__VA_ARGS__);                   \
+      return UFND_ERR_INVALID;                       \
+    }                                                \
+  } while (0)
+#define UFND_CHECK_LAUNCH()                                              \
+  do {                                                                   \
+    hipError_t e_ = hipGetLastError();                                   \
+    if (e_ != hipSuccess) {                                              \
+      ufnd_set_error("%s:%d launch failed: %s", __FILE__, __LINE__,      \
+                     hipGetErrorString(e_));                             \
+      return UFND_ERR_LAUNCH;                                            \
+    }                                                                    \
+  } while (0)
+
+static inline bool ufnd_aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+static inline int ufnd_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ------------------------------------------------------------------ math
+__device__ __forceinline__ float gelu_f(float x) {            // nn.GELU() default: exact erf
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ------------------------------------------------------------------ counter-based dropout RNG
+// Philox4x32-10 keyed by the run's seed; counter = (element, layer tag, step).  The same
+// (seed, step, layer, element) always yields the same keep/drop decision, so backward
+// regenerates the forward mask instead of storing it.
+__device__ __forceinline__ uint32_t philox_u32(uint64_t seed, uint64_t step, uint32_t layer, uint32_t elem) {
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  uint32_t c0 = elem, c1 = layer, c2 = (uint32_t)step, c3 = (uint32_t)(step >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return c0;
+}
+// multiplier applied to an activation: 0 (dropped) or 1/(1-p) (kept).  p == 0 -> 1.
+__device__ __forceinline__ float dropout_mul(const ufnd_step_state* st, float p, uint32_t layer, uint32_t elem) {
+  if (p <= 0.0f) return 1.0f;
+  const uint32_t r = philox_u32(st->seed, st->step, layer, elem);
+  const float u = (float)(r >> 8) * (1.0f / 16777216.0f);
+  return (u >= p) ? 1.0f / (1.0f - p) : 0.0f;
+}

@@ -1,0 +1,458 @@
+// fp32 skinny GEMMs on v_mfma_f32_32x32x2_f32 (see gemm_f32.hpp).
+//
+// MFMA 32x32x2 f32 operand maps (guide section 3): lane l, i = j = l & 31, h = l >> 5
+//   A[i][k=h], B[k=h][j];  C/D: column j = l & 31, row = (r & 3) + 8 * (r >> 2) + 4 * h, r in [0,16).
+// The contraction index may be permuted freely as long as A and B agree, so each lane loads
+// FOUR consecutive contraction elements (16 B) and feeds element e to MFMA step e: half h of
+// the wave covers k = kb + 4h + e of every 8-wide chunk.  The free index of the streamed
+// weight matrix is likewise permuted so that a lane owns VEC consecutive output columns.
+#include "gemm_f32.hpp"
+
+namespace {
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* p, float (&o)[4]) {
+  if constexpr (VEC == 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+  } else {
+    const f32x2 a = *reinterpret_cast<const f32x2*>(p);
+    const f32x2 b = *reinterpret_cast<const f32x2*>(p + 2);
+    o[0] = a[0]; o[1] = a[1]; o[2] = b[0]; o[3] = b[1];
+  }
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+  return z;
+}
+
+// ------------------------------------------------------------------------------------------
+// NT: Y = act(X W^T + b).   block = 4 waves splitting the block's K range; LDS tree-free sum.
+// ------------------------------------------------------------------------------------------
+struct NtArgs {
+  NtProb p[UFND_GEMM_MAX_PROB];
+  int begin[UFND_GEMM_MAX_PROB + 1];
+  int nprob;
+  const ufnd_step_state* st;
+};
+
+template <int MT, int WVEC>
+__global__ __launch_bounds__(256) void nt_kernel(const NtArgs args) {
+  __shared__ float red[4][MT][16][64];
+  int pi = 0;
+  for (int q = 1; q < args.nprob; ++q)
+    if ((int)blockIdx.x >= args.begin[q]) pi = q;
+  const NtProb& P = args.p[pi];
+  int local = blockIdx.x - args.begin[pi];
+  const int ks = local % P.ksplit;
+  local /= P.ksplit;
+  const int n_tiles = P.N >> 5;
+  const int n0 = (local % n_tiles) << 5;
+  const int m0 = (local / n_tiles) * (32 * MT);
+
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  // K range of this block, then of this wave (multiples of 8 except at the very end of K)
+  int kblk = (P.K + P.ksplit - 1) / P.ksplit;
+  kblk = (kblk + 31) & ~31;
+  const int kb0 = ks * kblk;
+  const int kb1 = min(P.K, kb0 + kblk);
+  const int sub = kblk >> 2;
+  const int k0 = kb0 + w * sub;
+  const int k1 = min(kb1, k0 + sub);
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) acc[t] = zero16();
+
+  const float* wrow = P.W + (size_t)(n0 + j) * P.ldw;
+  const float* xrow[MT];
+  bool xok[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int m = m0 + 32 * t + j;
+    xok[t] = m < P.M;
+    xrow[t] = P.X + (size_t)(xok[t] ? m : 0) * P.ldx;
+  }
+
+  int k = k0;
+#pragma unroll 4
+  for (; k + 8 <= k1; k += 8) {
+    const int kk = k + 4 * h;
+    float a[4];
+    load_vec<WVEC>(wrow + kk, a);
+    float b[MT][4];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      if (xok[t]) {
+        load_vec<4>(xrow[t] + kk, b[t]);
+      } else {
+        b[t][0] = b[t][1] = b[t][2] = b[t][3] = 0.0f;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[t][e], acc[t], 0, 0, 0);
+  }
+  if (k < k1) {  // ragged tail (K not a multiple of 8), element-guarded
+    const int kk = k + 4 * h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool ok = (kk + e) < k1;
+      const float a = ok ? wrow[kk + e] : 0.0f;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const float b = (ok && xok[t]) ? xrow[t][kk + e] : 0.0f;
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[w][t][r][lane] = acc[t][r];
+  __syncthreads();
+
+  // wave w finalises accumulator registers 4w..4w+3: rows n = n0 + 8w + 4h + q, column m
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] += red[ww][t][4 * w + q][lane];
+    const int m = m0 + 32 * t + j;
+    const int n = n0 + 8 * w + 4 * h;
+    if (m >= P.M) continue;
+    if (P.ksplit > 1) {
+      *reinterpret_cast<f32x4*>(P.Y + ((size_t)ks * P.M + m) * P.N + n) = v;
+      continue;
+    }
+    if (P.bias) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(P.bias + n);
+      v += bv;
+    }
+    if (P.Z) *reinterpret_cast<f32x4*>(P.Z + (size_t)m * P.ldz + n) = v;
+    if (P.act == 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = gelu_f(v[q]);
+    }
+    if (P.drop_p > 0.0f) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] *= dropout_mul(args.st, P.drop_p, P.drop_layer, (uint32_t)(m * P.N + n + q));
+    }
+    *reinterpret_cast<f32x4*>(P.Y + (size_t)m * P.ldy + n) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// NN: dX = dY W  (contraction over the weight's ROW index n; weight rows stream coalesced).
+// A wave owns a strip of 32*VEC output columns (lane j owns columns kc + VEC*j .. +VEC-1).
+// ------------------------------------------------------------------------------------------
+struct NnArgs {
+  NnProb p[UFND_GEMM_MAX_PROB];
+  int begin[UFND_GEMM_MAX_PROB + 1];
+  int nprob;
+  const ufnd_step_state* st;
+};
+
+template <int VEC>
+__global__ __launch_bounds__(256) void nn_kernel(const NnArgs args) {
+  __shared__ float red[4][VEC][16][64];
+  int pi = 0;
+  for (int q = 1; q < args.nprob; ++q)
+    if ((int)blockIdx.x >= args.begin[q]) pi = q;
+  const NnProb& P = args.p[pi];
+  int local = blockIdx.x - args.begin[pi];
+  const int ns = local % P.nsplit;
+  local /= P.nsplit;
+  const int strips = (P.K + 32 * VEC - 1) / (32 * VEC);
+  const int kc = (local % strips) * 32 * VEC;
+  const int m0 = (local / strips) * 32;
+
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  int nblk = (P.N + P.nsplit - 1) / P.nsplit;
+  nblk = (nblk + 31) & ~31;
+  const int nb0 = ns * nblk;
+  const int nb1 = min(P.N, nb0 + nblk);
+  const int sub = nblk >> 2;
+  const int n0 = nb0 + w * sub;
+  const int n1 = min(nb1, n0 + sub);  // N % 32 == 0 (host-checked) => multiples of 8
+
+  f32x16 acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = zero16();
+
+  const int m = m0 + j;
+  const bool mok = m < P.M;
+  const float* dyrow = P.dY + (size_t)(mok ? m : 0) * P.lddy;
+  const int kcol = kc + VEC * j;
+  const bool kok = kcol < P.K;  // K % VEC == 0 (host-checked)
+  const float* wcol = P.W + (kok ? kcol : 0);
+
+#pragma unroll 2
+  for (int n = n0; n < n1; n += 8) {
+    const int nn = n + 4 * h;
+    float a[4];
+    if (mok) {
+      load_vec<4>(dyrow + nn, a);
+    } else {
+      a[0] = a[1] = a[2] = a[3] = 0.0f;
+    }
+    float b[4][VEC];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float* src = wcol + (size_t)(nn + e) * P.ldw;
+      if (kok) {
+        if constexpr (VEC == 4) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(src);
+          b[e][0] = t[0]; b[e][1] = t[1]; b[e][2] = t[2]; b[e][3] = t[3];
+        } else {
+          const f32x2 t = *reinterpret_cast<const f32x2*>(src);
+          b[e][0] = t[0]; b[e][1] = t[1];
+        }
+      } else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) b[e][v] = 0.0f;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e][v], acc[v], 0, 0, 0);
+  }
+
+#pragma unroll
+  for (int v = 0; v < VEC; ++v)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[w][v][r][lane] = acc[v][r];
+  __syncthreads();
+
+  // wave w finalises registers 4w..4w+3: rows mrow = m0 + q + 8w + 4h, columns kc + VEC*j + v
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float val[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      float s = 0.0f;
+#pragma unroll
+      for (int ww = 0; ww < 4; ++ww) s += red[ww][v][4 * w + q][lane];
+      val[v] = s;
+    }
+    const int mrow = m0 + q + 8 * w + 4 * h;
+    if (mrow >= P.M || !kok) continue;
+    if (P.nsplit > 1) {
+      float* dst = P.out + ((size_t)ns * P.M + mrow) * P.K + kcol;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) dst[v] = val[v];
+      continue;
+    }
+    if (P.actZ) {
+      const float* z = P.actZ + (size_t)mrow * P.ldz + kcol;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        float g = gelu_grad_f(z[v]);
+        if (P.drop_p > 0.0f) g *= dropout_mul(args.st, P.drop_p, P.drop_layer, (uint32_t)(mrow * P.drop_ld + kcol + v));
+        val[v] *= g;
+      }
+    }
+    if (P.add) {
+      const float* ad = P.add + (size_t)mrow * P.ldadd + kcol;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) val[v] += ad[v];
+    }
+    float* dst = P.out + (size_t)mrow * P.ldo + kcol;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) dst[v] = val[v];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// TN: dW = dY^T X (contraction over the batch rows), db = column sums of dY.
+// One wave per (32 weight rows) x (32*VEC weight columns) tile; no LDS, no barrier.
+// ------------------------------------------------------------------------------------------
+struct TnArgs {
+  TnProb p[UFND_GEMM_MAX_PROB];
+  int begin[UFND_GEMM_MAX_PROB + 1];  // in wave-tiles
+  int nprob;
+};
+
+template <int VEC>
+__global__ __launch_bounds__(256) void tn_kernel(const TnArgs args) {
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  const int tile = blockIdx.x * 4 + w;
+  if (tile >= args.begin[args.nprob]) return;
+  int pi = 0;
+  for (int q = 1; q < args.nprob; ++q)
+    if (tile >= args.begin[q]) pi = q;
+  const TnProb& P = args.p[pi];
+  const int local = tile - args.begin[pi];
+  const int strips = (P.K + 32 * VEC - 1) / (32 * VEC);
+  const int strip = local % strips;
+  const int n0 = (local / strips) << 5;
+  const int kcol = strip * 32 * VEC + VEC * j;
+  const bool kok = kcol < P.K;
+
+  f32x16 acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = zero16();
+  float dbsum = 0.0f;
+  const float* dycol = P.dY + n0 + j;
+  const float* xcol = P.X + (kok ? kcol : 0);
+
+#pragma unroll 2
+  for (int mb = 0; mb < P.M; mb += 8) {
+    float a[4];
+    float b[4][VEC];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int m = mb + 4 * h + e;
+      const bool ok = m < P.M;
+      a[e] = ok ? dycol[(size_t)m * P.lddy] : 0.0f;
+      if (ok && kok) {
+        const float* src = xcol + (size_t)m * P.ldx;
+        if constexpr (VEC == 4) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(src);
+          b[e][0] = t[0]; b[e][1] = t[1]; b[e][2] = t[2]; b[e][3] = t[3];
+        } else {
+          const f32x2 t = *reinterpret_cast<const f32x2*>(src);
+          b[e][0] = t[0]; b[e][1] = t[1];
+        }
+      } else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) b[e][v] = 0.0f;
+      }
+      dbsum += a[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e][v], acc[v], 0, 0, 0);
+  }
+
+  if (kok) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      float* dst = P.dW + (size_t)n * P.ldw + kcol;
+      if constexpr (VEC == 4) {
+        f32x4 t = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+        *reinterpret_cast<f32x4*>(dst) = t;
+      } else {
+        f32x2 t = {acc[0][r], acc[1][r]};
+        *reinterpret_cast<f32x2*>(dst) = t;
+      }
+    }
+  }
+  if (strip == 0 && P.db) {
+    const float s = dbsum + __shfl_xor(dbsum, 32, 64);
+    if (h == 0) P.db[n0 + j] = s;
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// host launchers (argument checks guard every assumption the kernels make)
+// ------------------------------------------------------------------------------------------
+int launch_nt(const NtProb* probs, int nprob, const ufnd_step_state* st, hipStream_t stream) {
+  UFND_REQUIRE(nprob >= 1 && nprob <= UFND_GEMM_MAX_PROB, "nt: %d problems", nprob);
+  NtArgs a;
+  a.nprob = nprob;
+  a.st = st;
+  int total = 0, maxM = 0;
+  bool vec4 = true;
+  for (int i = 0; i < nprob; ++i) {
+    const NtProb& p = probs[i];
+    UFND_REQUIRE(p.X && p.W && p.Y && p.M > 0 && p.K > 0, "nt[%d]: null/empty operand", i);
+    UFND_REQUIRE(p.N % 32 == 0, "nt[%d]: N=%d not a multiple of 32", i, p.N);
+    UFND_REQUIRE(p.ldx % 4 == 0 && ufnd_aligned(p.X, 16), "nt[%d]: X must be 16-B aligned with ldx%%4==0", i);
+    UFND_REQUIRE(p.ldw % 2 == 0 && ufnd_aligned(p.W, 8), "nt[%d]: W must be 8-B aligned with even ldw", i);
+    UFND_REQUIRE(p.ksplit >= 1 && p.ksplit <= 64, "nt[%d]: ksplit=%d", i, p.ksplit);
+    UFND_REQUIRE(ufnd_aligned(p.Y, 16) && (p.ksplit > 1 || p.ldy % 4 == 0), "nt[%d]: Y alignment", i);
+    UFND_REQUIRE(!p.Z || (ufnd_aligned(p.Z, 16) && p.ldz % 4 == 0), "nt[%d]: Z alignment", i);
+    UFND_REQUIRE(!p.bias || ufnd_aligned(p.bias, 16), "nt[%d]: bias alignment", i);
+    UFND_REQUIRE((long long)p.M * p.N < (1ll << 31), "nt[%d]: M*N too large", i);
+    if (!(p.ldw % 4 == 0 && ufnd_aligned(p.W, 16))) vec4 = false;
+    a.p[i] = p;
+    maxM = p.M > maxM ? p.M : maxM;
+  }
+  const int MT = maxM > 32 ? 2 : 1;
+  for (int i = 0; i < nprob; ++i) {
+    a.begin[i] = total;
+    total += (a.p[i].N / 32) * ufnd_cdiv(a.p[i].M, 32 * MT) * a.p[i].ksplit;
+  }
+  a.begin[nprob] = total;
+  if (MT == 1) {
+    if (vec4) hipLaunchKernelGGL((nt_kernel<1, 4>), dim3(total), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((nt_kernel<1, 2>), dim3(total), dim3(256), 0, stream, a);
+  } else {
+    if (vec4) hipLaunchKernelGGL((nt_kernel<2, 4>), dim3(total), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((nt_kernel<2, 2>), dim3(total), dim3(256), 0, stream, a);
+  }
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}
+
+int launch_nn(const NnProb* probs, int nprob, const ufnd_step_state* st, hipStream_t stream) {
+  UFND_REQUIRE(nprob >= 1 && nprob <= UFND_GEMM_MAX_PROB, "nn: %d problems", nprob);
+  NnArgs a;
+  a.nprob = nprob;
+  a.st = st;
+  bool vec4 = true;
+  for (int i = 0; i < nprob; ++i) {
+    const NnProb& p = probs[i];
+    UFND_REQUIRE(p.dY && p.W && p.out && p.M > 0 && p.K > 0, "nn[%d]: null/empty operand", i);
+    UFND_REQUIRE(p.N % 32 == 0, "nn[%d]: N=%d not a multiple of 32", i, p.N);
+    UFND_REQUIRE(p.lddy % 4 == 0 && ufnd_aligned(p.dY, 16), "nn[%d]: dY alignment", i);
+    UFND_REQUIRE(p.K % 2 == 0 && p.ldw % 2 == 0 && ufnd_aligned(p.W, 8), "nn[%d]: W alignment", i);
+    UFND_REQUIRE(p.nsplit >= 1 && p.nsplit <= 64, "nn[%d]: nsplit=%d", i, p.nsplit);
+    UFND_REQUIRE((long long)p.M * p.K < (1ll << 31), "nn[%d]: M*K too large", i);
+    if (!(p.K % 4 == 0 && p.ldw % 4 == 0 && ufnd_aligned(p.W, 16))) vec4 = false;
+    a.p[i] = p;
+  }
+  const int VEC = vec4 ? 4 : 2;
+  int total = 0;
+  for (int i = 0; i < nprob; ++i) {
+    a.begin[i] = total;
+    total += ufnd_cdiv(a.p[i].K, 32 * VEC) * ufnd_cdiv(a.p[i].M, 32) * a.p[i].nsplit;
+  }
+  a.begin[nprob] = total;
+  if (vec4) hipLaunchKernelGGL((nn_kernel<4>), dim3(total), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((nn_kernel<2>), dim3(total), dim3(256), 0, stream, a);
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}
+
+int launch_tn(const TnProb* probs, int nprob, hipStream_t stream) {
+  UFND_REQUIRE(nprob >= 1 && nprob <= UFND_GEMM_MAX_PROB, "tn: %d problems", nprob);
+  TnArgs a;
+  a.nprob = nprob;
+  bool vec4 = true;
+  for (int i = 0; i < nprob; ++i) {
+    const TnProb& p = probs[i];
+    UFND_REQUIRE(p.dY && p.X && p.dW && p.M > 0 && p.K > 0, "tn[%d]: null/empty operand", i);
+    UFND_REQUIRE(p.N % 32 == 0, "tn[%d]: N=%d not a multiple of 32", i, p.N);
+    UFND_REQUIRE(p.K % 2 == 0 && p.ldx % 2 == 0 && p.ldw % 2 == 0 && ufnd_aligned(p.X, 8) && ufnd_aligned(p.dW, 8),
+                 "tn[%d]: X/dW alignment", i);
+    if (!(p.K % 4 == 0 && p.ldx % 4 == 0 && p.ldw % 4 == 0 && ufnd_aligned(p.X, 16) && ufnd_aligned(p.dW, 16)))
+      vec4 = false;
+    a.p[i] = p;
+  }
+  const int VEC = vec4 ? 4 : 2;
+  int total = 0;
+  for (int i = 0; i < nprob; ++i) {
+    a.begin[i] = total;
+    total += (a.p[i].N / 32) * ufnd_cdiv(a.p[i].K, 32 * VEC);
+  }
+  a.begin[nprob] = total;
+  const int blocks = ufnd_cdiv(total, 4);
+  if (vec4) hipLaunchKernelGGL((tn_kernel<4>), dim3(blocks), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((tn_kernel<2>), dim3(blocks), dim3(256), 0, stream, a);
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}

@@ -1,0 +1,108 @@
+// clip_grad_norm_ + AdamW over one flat fp32 arena (forensic_trainer.py:292-298,176).
+// The reference runs ~104 per-tensor norm kernels and a foreach AdamW (56 % of its step,
+// SURVEY.md 3); here parameters, gradients and both moments are four flat HBM arrays, so the
+// whole optimizer is two streaming passes: 4 B/param read for the norm, 28 B/param for AdamW.
+#include "common.hpp"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, size_t n4, float* partials) {
+  __shared__ float sh[4];
+  float s = 0.0f;
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 v = g4[i];
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// one block: fixed-order sum of the partials (bit-reproducible), then the step's scalars
+__global__ __launch_bounds__(256) void norm_finalize_kernel(const float* partials, int nblocks, ufnd_step_state* st) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) s += (double)partials[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float total = (float)sqrt(sh[0]) * fabsf(st->grad_scale);
+    st->grad_norm = total;
+    float coef = 1.0f;
+    if (st->max_norm > 0.0f) coef = fminf(1.0f, st->max_norm / (total + 1e-6f));
+    st->clip_coef = coef;
+    const double t = (double)(st->step + 1);
+    st->bc1 = (float)(1.0 - pow((double)st->beta1, t));
+    st->bc2_sqrt = (float)sqrt(1.0 - pow((double)st->beta2, t));
+  }
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, size_t n4,
+                                                    const ufnd_step_state* st) {
+  const float lr = st->lr, b1 = st->beta1, b2 = st->beta2, eps = st->eps;
+  const float decay = 1.0f - lr * st->weight_decay;
+  const float gs = st->grad_scale * st->clip_coef;
+  const float step_size = lr / st->bc1, inv_bc2 = 1.0f / st->bc2_sqrt;
+  f32x4* p4 = reinterpret_cast<f32x4*>(p);
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+  f32x4* m4 = reinterpret_cast<f32x4*>(m);
+  f32x4* v4 = reinterpret_cast<f32x4*>(v);
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    f32x4 pp = p4[i], mm = m4[i], vv = v4[i];
+    const f32x4 gg = g4[i] * gs;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float gq = gg[q];
+      float pq = pp[q] * decay;
+      const float mq = mm[q] * b1 + (1.0f - b1) * gq;
+      const float vq = vv[q] * b2 + (1.0f - b2) * gq * gq;
+      const float denom = sqrtf(vq) * inv_bc2 + eps;
+      pq -= step_size * (mq / denom);
+      pp[q] = pq; mm[q] = mq; vv[q] = vq;
+    }
+    p4[i] = pp; m4[i] = mm; v4[i] = vv;
+  }
+}
+
+__global__ void step_advance_kernel(ufnd_step_state* st) { st->step += 1; }
+
+}  // namespace
+
+extern "C" int ufnd_grad_norm(const float* grad, size_t n, float* partials, ufnd_step_state* state, void* stream_) {
+  UFND_REQUIRE(grad && partials && state && n > 0, "grad_norm: null argument");
+  UFND_REQUIRE(n % 4 == 0 && ufnd_aligned(grad, 16), "grad_norm: n %% 4 == 0 and 16-B alignment required");
+  hipStream_t stream = (hipStream_t)stream_;
+  size_t want = (n / 4 + 1023) / 1024;  // >= 4 float4 per thread
+  const int blocks = (int)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
+  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, stream, grad, n / 4, partials);
+  UFND_CHECK_LAUNCH();
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3(1), dim3(256), 0, stream, (const float*)partials, blocks, state);
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}
+
+extern "C" int ufnd_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                               const ufnd_step_state* state, void* stream_) {
+  UFND_REQUIRE(param && grad && exp_avg && exp_avg_sq && state && n > 0, "adamw_step: null argument");
+  UFND_REQUIRE(n % 4 == 0 && ufnd_aligned(param, 16) && ufnd_aligned(grad, 16) && ufnd_aligned(exp_avg, 16) &&
+                   ufnd_aligned(exp_avg_sq, 16), "adamw_step: n %% 4 == 0 and 16-B alignment required");
+  size_t want = (n / 4 + 511) / 512;
+  const int blocks = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+  hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, param, grad, exp_avg, exp_avg_sq,
+                     n / 4, state);
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}
+
+extern "C" int ufnd_step_advance(ufnd_step_state* state, void* stream_) {
+  UFND_REQUIRE(state, "step_advance: null state");
+  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, state);
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}

@@ -1,0 +1,869 @@
+// Tier-A head: CrossModalTransformer + DeepTruthClassifier forward / backward, cross-entropy.
+// Reference arithmetic: src/models/fusion/cross_modal_transformer.py:39-55,134-210 and
+// src/models/fusion/deep_truth_classifier.py:54-74,88-90,148-171 (fp32 throughout).
+//
+// Data layout (per call, B rows, H = hidden):
+//   CAT  (B, 16H)  the fuse_mlp input, written in place by its producers -- slot order
+//        [t a v u | t+a t*a |t-a| t+v t*v |t-v| t+u v+u | tv* ta* vu* | g]   (:172-195)
+//   QKV  (B, 9H)   stacked co-attention projections, column blocks
+//        [q_tv q_ta | k_tv v_tv q_vu | k_ta v_ta | k_vu v_vu]  so that each source vector
+//        (t, v, a, u) feeds ONE stacked GEMM forward and ONE stacked GEMM backward.
+// Row kernels use one 64-lane wave per sample; lane l owns columns 4l..4l+3 (+256 i).
+#include "gemm_f32.hpp"
+
+namespace {
+
+constexpr uint32_t LAYER_FUSE0 = 1, LAYER_FUSE3 = 2, LAYER_PRE0 = 3, LAYER_PRE3 = 4, LAYER_TREE = 5;
+constexpr int KSPLIT_FUSE0 = 16;  // fuse_mlp.0 forward: K = 16H split 16 ways (x4 waves in-block)
+constexpr int NSPLIT_FUSE0 = 4;   // fuse_mlp.0 dX: contraction 2H split 4 ways (x4 waves in-block)
+
+inline size_t al64(size_t n) { return (n + 63) & ~(size_t)63; }
+
+// ---------------------------------------------------------------- workspaces
+struct FusionWs {
+  float *cat, *qkv, *evid, *gate, *s, *part1, *z1, *h1, *z2;
+  float *dz2, *dz1, *dcatp, *dtavu, *dg, *dqkv, *dout;
+  size_t total;
+};
+FusionWs carve_fusion(const ufnd_dims& d, int B, float* base) {
+  const size_t H = d.hidden;
+  FusionWs w;
+  size_t o = 0;
+  auto take = [&](size_t n) { float* p = base ? base + o : nullptr; o += al64(n); return p; };
+  w.cat = take((size_t)B * 16 * H);
+  w.qkv = take((size_t)B * 9 * H);
+  w.evid = take((size_t)B * 4);
+  w.gate = take((size_t)B * 4);
+  w.s = take((size_t)B * 4);
+  w.part1 = take((size_t)KSPLIT_FUSE0 * B * 2 * H);
+  w.z1 = take((size_t)B * 2 * H);
+  w.h1 = take((size_t)B * 2 * H);
+  w.z2 = take((size_t)B * H);
+  w.dz2 = take((size_t)B * H);
+  w.dz1 = take((size_t)B * 2 * H);
+  w.dcatp = take((size_t)NSPLIT_FUSE0 * B * 16 * H);
+  w.dtavu = take((size_t)4 * B * H);
+  w.dg = take((size_t)B * H);
+  w.dqkv = take((size_t)B * 9 * H);
+  w.dout = take((size_t)B * 4);
+  w.total = o;
+  return w;
+}
+
+struct ClfWs {
+  float *xin, *z3, *h3, *z4, *hh, *alpha, *fs, *df, *dz4, *dz3, *dl;
+  int ldx;
+  size_t total;
+};
+ClfWs carve_clf(const ufnd_dims& d, int B, float* base) {
+  const size_t H = d.hidden;
+  ClfWs w;
+  size_t o = 0;
+  auto take = [&](size_t n) { float* p = base ? base + o : nullptr; o += al64(n); return p; };
+  w.ldx = d.hidden + 4;  // [fused | aux (<= 4) | zero pad]; row stride stays a multiple of 4
+  w.xin = take((size_t)B * w.ldx);
+  w.z3 = take((size_t)B * H);
+  w.h3 = take((size_t)B * H);
+  w.z4 = take((size_t)B * H);
+  w.hh = take((size_t)B * H);
+  w.alpha = take((size_t)d.trees * d.depth * H);
+  w.fs = take((size_t)B * 64);
+  w.df = take((size_t)B * 64);
+  w.dz4 = take((size_t)B * H);
+  w.dz3 = take((size_t)B * H);
+  w.dl = take((size_t)B * 4);
+  w.total = o;
+  return w;
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ float dot4(f32x4 a, f32x4 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
+__device__ __forceinline__ float sgn(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
+
+// ---------------------------------------------------------------- split-K epilogue
+// Y = drop(act(sum_s PART[s] + bias)), Z = pre-activation.   (M*N % 4 == 0)
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* part, int nsplit, int M, int N,
+                                                              const float* bias, float* Z, float* Y, int act,
+                                                              float drop_p, uint32_t layer,
+                                                              const ufnd_step_state* st) {
+  const size_t total4 = (size_t)M * N / 4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = i * 4;
+    const int n = (int)(e % N);
+    f32x4 v = ld4(part + e);
+    for (int s = 1; s < nsplit; ++s) v += ld4(part + (size_t)s * M * N + e);
+    if (bias) v += ld4(bias + n);
+    if (Z) st4(Z + e, v);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float x = v[q];
+      if (act == 1) x = gelu_f(x);
+      x *= dropout_mul(st, drop_p, layer, (uint32_t)(e + q));
+      v[q] = x;
+    }
+    st4(Y + e, v);
+  }
+}
+
+// ---------------------------------------------------------------- evidence scalars + gates
+// cross_modal_transformer.py:153-164 (no_grad scalars) and :48 (evidence_proj -> sigmoid)
+struct EvPtrs {
+  const float *w0[3], *b0[3], *w2[3], *b2[3];
+};
+struct EvGrads {
+  float *w0[3], *b0[3], *w2[3], *b2[3];
+};
+template <int NI>
+__global__ __launch_bounds__(256) void evidence_gate_kernel(const float* cat, int B, int H, EvPtrs ev, float* evid,
+                                                            float* gate, float* forensic) {
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= B) return;
+  const float* c = cat + (size_t)row * 16 * H;
+  float tt = 0, vv = 0, uu = 0, tv = 0, tu = 0, ta = 0;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int col = 4 * lane + 256 * i;
+    const f32x4 t = ld4(c + col), v = ld4(c + 2 * H + col), u = ld4(c + 3 * H + col);
+    tt += dot4(t, t); vv += dot4(v, v); uu += dot4(u, u); tv += dot4(t, v); tu += dot4(t, u);
+    ta += fabsf(t[0]) + fabsf(t[1]) + fabsf(t[2]) + fabsf(t[3]);
+  }
+  tt = wave_sum(tt); vv = wave_sum(vv); uu = wave_sum(uu); tv = wave_sum(tv); tu = wave_sum(tu); ta = wave_sum(ta);
+  const float nt = fmaxf(sqrtf(tt), 1e-12f), nv = fmaxf(sqrtf(vv), 1e-12f), nu = fmaxf(sqrtf(uu), 1e-12f);
+  const float conf = 1.0f - 0.5f * (fminf(fmaxf(tv / (nt * nv), -1.0f), 1.0f) + 1.0f);
+  const float delay = 1.0f - 0.5f * (fminf(fmaxf(tu / (nt * nu), -1.0f), 1.0f) + 1.0f);
+  const float emo = tanhf(ta / (float)H);
+  const float e[3][3] = {{conf, emo, 0.f}, {emo, 0.f, 0.f}, {delay, 0.f, 0.f}};
+  float g[3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    float o = 0.0f;
+    for (int jj = lane; jj < H; jj += 64) {
+      const float pre = ev.w0[b][jj * 3 + 0] * e[b][0] + ev.w0[b][jj * 3 + 1] * e[b][1] +
+                        ev.w0[b][jj * 3 + 2] * e[b][2] + ev.b0[b][jj];
+      o += ev.w2[b][jj] * gelu_f(pre);
+    }
+    g[b] = sigmoid_f(wave_sum(o) + ev.b2[b][0]);
+  }
+  if (lane == 0) {
+    st4(evid + (size_t)row * 4, f32x4{conf, emo, delay, 0.f});
+    st4(gate + (size_t)row * 4, f32x4{g[0], g[1], g[2], 0.f});
+    forensic[row] = emo;              // emotion_intensity
+    forensic[B + row] = conf;         // semantic_conflict
+    forensic[2 * B + row] = delay;    // temporal_delay
+  }
+}
+
+// ---------------------------------------------------------------- co-attention + pairwise -> CAT
+// cross_modal_transformer.py:44-54 and :172-178
+template <int NI>
+__global__ __launch_bounds__(256) void coattn_pairs_kernel(float* cat, const float* qkv, const float* gate, int B,
+                                                           int H, float* s_out) {
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= B) return;
+  float* c = cat + (size_t)row * 16 * H;
+  const float* q = qkv + (size_t)row * 9 * H;
+  const int QI[3] = {0, 1, 4}, KI[3] = {2, 5, 7}, VI[3] = {3, 6, 8};
+  const int XS[3] = {0, 0, 2}, YS[3] = {2, 1, 3};
+  float dots[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int b = 0; b < 3; ++b)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int col = 4 * lane + 256 * i;
+      dots[b] += dot4(ld4(q + QI[b] * H + col), ld4(q + KI[b] * H + col));
+    }
+  float s[3];
+  const float inv = 1.0f / sqrtf((float)H);
+#pragma unroll
+  for (int b = 0; b < 3; ++b) s[b] = sigmoid_f(wave_sum(dots[b]) * inv);
+  const f32x4 gt = ld4(gate + (size_t)row * 4);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int col = 4 * lane + 256 * i;
+    const f32x4 t = ld4(c + col), a = ld4(c + H + col), v = ld4(c + 2 * H + col), u = ld4(c + 3 * H + col);
+    f32x4 ab;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ab[k] = fabsf(t[k] - a[k]);
+    st4(c + 4 * H + col, t + a);
+    st4(c + 5 * H + col, t * a);
+    st4(c + 6 * H + col, ab);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ab[k] = fabsf(t[k] - v[k]);
+    st4(c + 7 * H + col, t + v);
+    st4(c + 8 * H + col, t * v);
+    st4(c + 9 * H + col, ab);
+    st4(c + 10 * H + col, t + u);
+    st4(c + 11 * H + col, v + u);
+    const f32x4 xs[4] = {t, a, v, u};
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const f32x4 val = ld4(q + VI[b] * H + col);
+      const f32x4 base = 0.5f * (xs[XS[b]] + xs[YS[b]]);
+      st4(c + (12 + b) * H + col, gt[b] * (s[b] * val) + (1.0f - gt[b]) * base);
+    }
+  }
+  if (lane == 0) st4(s_out + (size_t)row * 4, f32x4{s[0], s[1], s[2], 0.f});
+}
+
+// backward of the above.  dcatp: [nsplit][B][16H] partial sums of dCAT.
+template <int NI>
+__global__ __launch_bounds__(256) void coattn_pairs_bwd_kernel(const float* dcatp, int nsplit, const float* cat,
+                                                               const float* qkv, const float* gate, const float* s_in,
+                                                               int B, int H, float* dtavu, float* dqkv, float* dg,
+                                                               float* dout) {
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= B) return;
+  const float* c = cat + (size_t)row * 16 * H;
+  const float* q = qkv + (size_t)row * 9 * H;
+  const int QI[3] = {0, 1, 4}, KI[3] = {2, 5, 7}, VI[3] = {3, 6, 8};
+  const int XS[3] = {0, 0, 2}, YS[3] = {2, 1, 3};
+  auto G = [&](int slot, int col) {
+    f32x4 v = ld4(dcatp + (size_t)row * 16 * H + slot * H + col);
+    for (int p = 1; p < nsplit; ++p) v += ld4(dcatp + ((size_t)p * B + row) * 16 * H + slot * H + col);
+    return v;
+  };
+  const f32x4 gt = ld4(gate + (size_t)row * 4), sv = ld4(s_in + (size_t)row * 4);
+  // pass 1: the two row reductions of every block
+  float r_dg[3] = {0, 0, 0}, r_ds[3] = {0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int col = 4 * lane + 256 * i;
+    const f32x4 xs[4] = {ld4(c + col), ld4(c + H + col), ld4(c + 2 * H + col), ld4(c + 3 * H + col)};
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const f32x4 d = G(12 + b, col), val = ld4(q + VI[b] * H + col);
+      r_dg[b] += dot4(d, sv[b] * val - 0.5f * (xs[XS[b]] + xs[YS[b]]));
+      r_ds[b] += dot4(d, val);
+    }
+  }
+  const float inv = 1.0f / sqrtf((float)H);
+  float dscore[3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    const float dgate = wave_sum(r_dg[b]);
+    const float ds = gt[b] * wave_sum(r_ds[b]);
+    dscore[b] = ds * sv[b] * (1.0f - sv[b]) * inv;
+    r_dg[b] = dgate * gt[b] * (1.0f - gt[b]);  // gradient at the gate's pre-sigmoid output
+  }
+  if (lane == 0) st4(dout + (size_t)row * 4, f32x4{r_dg[0], r_dg[1], r_dg[2], 0.f});
+  // pass 2
+  float* dq = dqkv + (size_t)row * 9 * H;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int col = 4 * lane + 256 * i;
+    const f32x4 t = ld4(c + col), a = ld4(c + H + col), v = ld4(c + 2 * H + col), u = ld4(c + 3 * H + col);
+    const f32x4 g4 = G(4, col), g5 = G(5, col), g6 = G(6, col), g7 = G(7, col), g8 = G(8, col), g9 = G(9, col),
+                g10 = G(10, col), g11 = G(11, col);
+    f32x4 sta, stv;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sta[k] = sgn(t[k] - a[k]); stv[k] = sgn(t[k] - v[k]); }
+    f32x4 d[4];
+    d[0] = G(0, col) + g4 + g5 * a + g6 * sta + g7 + g8 * v + g9 * stv + g10;
+    d[1] = G(1, col) + g4 + g5 * t - g6 * sta;
+    d[2] = G(2, col) + g7 + g8 * t - g9 * stv + g11;
+    d[3] = G(3, col) + g10 + g11;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const f32x4 dob = G(12 + b, col);
+      const f32x4 half = (0.5f * (1.0f - gt[b])) * dob;
+      d[XS[b]] += half;
+      d[YS[b]] += half;
+      st4(dq + VI[b] * H + col, (gt[b] * sv[b]) * dob);
+      st4(dq + QI[b] * H + col, dscore[b] * ld4(q + KI[b] * H + col));
+      st4(dq + KI[b] * H + col, dscore[b] * ld4(q + QI[b] * H + col));
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) st4(dtavu + ((size_t)x * B + row) * H + col, d[x]);
+    st4(dg + (size_t)row * H + col, G(15, col));
+  }
+}
+
+// evidence_proj parameter gradients: one block per co-attention block, thread j = hidden unit
+__global__ void gate_param_kernel(const float* evid, const float* dout, int B, int H, EvPtrs p, EvGrads g) {
+  const int b = blockIdx.x;
+  float db2 = 0.0f;
+  for (int jj = threadIdx.x; jj < H; jj += blockDim.x) {
+    const float w00 = p.w0[b][jj * 3], w01 = p.w0[b][jj * 3 + 1], w02 = p.w0[b][jj * 3 + 2], b0 = p.b0[b][jj],
+                w2 = p.w2[b][jj];
+    float dw0[3] = {0, 0, 0}, db0 = 0, dw2 = 0;
+    for (int r = 0; r < B; ++r) {
+      const f32x4 ev = ld4(evid + (size_t)r * 4);
+      float e[3];
+      if (b == 0) { e[0] = ev[0]; e[1] = ev[1]; e[2] = 0.f; }
+      else if (b == 1) { e[0] = ev[1]; e[1] = 0.f; e[2] = 0.f; }
+      else { e[0] = ev[2]; e[1] = 0.f; e[2] = 0.f; }
+      const float pre = w00 * e[0] + w01 * e[1] + w02 * e[2] + b0;
+      const float d_o = dout[(size_t)r * 4 + b];
+      dw2 += d_o * gelu_f(pre);
+      const float dpre = d_o * w2 * gelu_grad_f(pre);
+      dw0[0] += dpre * e[0]; dw0[1] += dpre * e[1]; dw0[2] += dpre * e[2];
+      db0 += dpre;
+    }
+    g.w0[b][jj * 3] = dw0[0]; g.w0[b][jj * 3 + 1] = dw0[1]; g.w0[b][jj * 3 + 2] = dw0[2];
+    g.b0[b][jj] = db0;
+    g.w2[b][jj] = dw2;
+  }
+  if (threadIdx.x == 0) {
+    for (int r = 0; r < B; ++r) db2 += dout[(size_t)r * 4 + b];
+    g.b2[b][0] = db2;
+  }
+}
+
+// dZ = (dY + dlog @ Wc) * gelu'(Z) * dropmask        (entry of the fusion backward)
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* dY, int ldd, const float* dlog, const float* wc,
+                                                      const float* Z, float* dZ, int M, int N, float drop_p,
+                                                      uint32_t layer, const ufnd_step_state* st) {
+  const size_t total = (size_t)M * N;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / N), n = (int)(i % N);
+    float d = dY ? dY[(size_t)m * ldd + n] : 0.0f;
+    if (dlog) d += dlog[m * 2] * wc[n] + dlog[m * 2 + 1] * wc[N + n];
+    dZ[i] = d * gelu_grad_f(Z[i]) * dropout_mul(st, drop_p, layer, (uint32_t)i);
+  }
+}
+
+// aux head: logits = fused Wc^T + bc (classes = 2); one wave per row
+__global__ __launch_bounds__(256) void head2_fwd_kernel(const float* x, int ldx, const float* w, const float* b,
+                                                        float* out, int B, int H) {
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wv;
+  if (row >= B) return;
+  float a0 = 0, a1 = 0;
+  for (int c = lane; c < H; c += 64) {
+    const float xv = x[(size_t)row * ldx + c];
+    a0 += xv * w[c];
+    a1 += xv * w[H + c];
+  }
+  a0 = wave_sum(a0); a1 = wave_sum(a1);
+  if (lane == 0) { out[row * 2] = a0 + b[0]; out[row * 2 + 1] = a1 + b[1]; }
+}
+// its parameter gradients; fused is recomputed from Z2 (gelu + dropout mask)
+__global__ void head2_bwd_kernel(const float* dlog, const float* Z, int B, int H, float drop_p, uint32_t layer,
+                                 const ufnd_step_state* st, float* dw, float* db) {
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < H; c += gridDim.x * blockDim.x) {
+    float s0 = 0, s1 = 0;
+    for (int r = 0; r < B; ++r) {
+      const size_t i = (size_t)r * H + c;
+      const float f = gelu_f(Z[i]) * dropout_mul(st, drop_p, layer, (uint32_t)i);
+      s0 += dlog[r * 2] * f;
+      s1 += dlog[r * 2 + 1] * f;
+    }
+    dw[c] = s0;
+    dw[H + c] = s1;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 2) {
+    float s = 0;
+    for (int r = 0; r < B; ++r) s += dlog[r * 2 + threadIdx.x];
+    db[threadIdx.x] = s;
+  }
+}
+
+// ---------------------------------------------------------------- classifier pieces
+__global__ void pack_xin_kernel(const float* fused, int ldf, const float* aux, int aux_dim, float* xin, int ldx,
+                                int B, int H, int copy_fused) {
+  const int row = blockIdx.x;
+  if (row >= B) return;
+  if (copy_fused)
+    for (int c = threadIdx.x; c < H; c += blockDim.x) xin[(size_t)row * ldx + c] = fused[(size_t)row * ldf + c];
+  if (threadIdx.x < 4)
+    xin[(size_t)row * ldx + H + threadIdx.x] = (aux && (int)threadIdx.x < aux_dim) ? aux[row * aux_dim + threadIdx.x] : 0.0f;
+}
+
+// alpha[tk] = softmax(gates[tk])                        deep_truth_classifier.py:64
+__global__ __launch_bounds__(256) void alpha_kernel(const float* gates, float* alpha, int H) {
+  __shared__ float sh[4];
+  const float* gp = gates + (size_t)blockIdx.x * H;
+  float mx = -INFINITY;
+  for (int c = threadIdx.x; c < H; c += 256) mx = fmaxf(mx, gp[c]);
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+  __syncthreads();
+  float s = 0;
+  for (int c = threadIdx.x; c < H; c += 256) s += __expf(gp[c] - mx);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  s = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  for (int c = threadIdx.x; c < H; c += 256) alpha[(size_t)blockIdx.x * H + c] = __expf(gp[c] - mx) / s;
+}
+
+// NODE ensemble + bypass + temperature softmax        deep_truth_classifier.py:54-74,88-90,164-170
+template <int NI>
+__global__ __launch_bounds__(256) void node_head_kernel(const float* hh, const float* alpha, const float* thresh,
+                                                        const float* leaf, const float* tau, const float* bw,
+                                                        const float* bb, const float* temperature, int B, int H,
+                                                        int trees, int depth, float node_p,
+                                                        const ufnd_step_state* st, float* fs, float* logits,
+                                                        float* probs) {
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= B) return;
+  f32x4 h[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) h[i] = ld4(hh + (size_t)row * H + 4 * lane + 256 * i);
+  const int TK = trees * depth;
+  float my_s = 0.0f;
+  for (int tk = 0; tk < TK; ++tk) {
+    float p = 0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) p += dot4(h[i], ld4(alpha + (size_t)tk * H + 4 * lane + 256 * i));
+    const float f = wave_sum(p);
+    const float s = sigmoid_f(tau[tk / depth] * (f - thresh[tk]));
+    if (lane == tk) my_s = s;
+  }
+  if (lane < TK) fs[(size_t)row * 64 + lane] = my_s;
+  float byp[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    float p = 0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) p += dot4(h[i], ld4(bw + (size_t)c * H + 4 * lane + 256 * i));
+    byp[c] = wave_sum(p) + bb[c];
+  }
+  const int leaves = 1 << depth;
+  float lg[2] = {0.f, 0.f};
+  for (int t = 0; t < trees; ++t) {
+    float prob = 1.0f;
+    for (int k = 0; k < depth; ++k) {
+      const float sk = __shfl(my_s, t * depth + k, 64);
+      prob *= ((lane >> k) & 1) ? sk : (1.0f - sk);
+    }
+    if (lane >= leaves) prob = 0.0f;
+    const float* lf = leaf + ((size_t)t * leaves + (lane < leaves ? lane : 0)) * 2;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float tl = wave_sum(prob * lf[c]);
+      lg[c] += tl * dropout_mul(st, node_p, LAYER_TREE, (uint32_t)((row * trees + t) * 2 + c));
+    }
+  }
+  if (lane == 0) {
+    const float l0 = lg[0] / (float)trees + byp[0], l1 = lg[1] / (float)trees + byp[1];
+    logits[row * 2] = l0;
+    logits[row * 2 + 1] = l1;
+    const float T = fminf(fmaxf(temperature[0], 0.5f), 5.0f);
+    const float a0 = l0 / T, a1 = l1 / T, mx = fmaxf(a0, a1);
+    const float e0 = __expf(a0 - mx), e1 = __expf(a1 - mx);
+    probs[row * 2] = e0 / (e0 + e1);
+    probs[row * 2 + 1] = e1 / (e0 + e1);
+  }
+}
+
+// backward through logits = mean_t(drop(probs_t @ leaf_t)) + bypass(h), down to dZ4
+template <int NI>
+__global__ __launch_bounds__(256) void node_bwd_kernel(const float* dlog, const float* fs, const float* alpha,
+                                                       const float* leaf, const float* tau, const float* bw,
+                                                       const float* z4, int B, int H, int trees, int depth,
+                                                       float node_p, float clf_p, const ufnd_step_state* st,
+                                                       float* df, float* dz4) {
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= B) return;
+  const float dl0 = dlog[row * 2], dl1 = dlog[row * 2 + 1];
+  const int TK = trees * depth, leaves = 1 << depth;
+  float my_df = 0.0f;
+  if (lane < TK) {
+    const int t = lane / depth, k = lane % depth;
+    const float d0 = dl0 / (float)trees * dropout_mul(st, node_p, LAYER_TREE, (uint32_t)((row * trees + t) * 2));
+    const float d1 = dl1 / (float)trees * dropout_mul(st, node_p, LAYER_TREE, (uint32_t)((row * trees + t) * 2 + 1));
+    float ds = 0.0f;
+    for (int l = 0; l < leaves; ++l) {
+      float prod = 1.0f;
+      for (int jj = 0; jj < depth; ++jj) {
+        if (jj == k) continue;
+        const float sj = fs[(size_t)row * 64 + t * depth + jj];
+        prod *= ((l >> jj) & 1) ? sj : (1.0f - sj);
+      }
+      const float* lf = leaf + ((size_t)t * leaves + l) * 2;
+      const float dprob = lf[0] * d0 + lf[1] * d1;
+      ds += (((l >> k) & 1) ? dprob : -dprob) * prod;
+    }
+    const float sk = fs[(size_t)row * 64 + lane];
+    my_df = ds * tau[t] * sk * (1.0f - sk);
+    df[(size_t)row * 64 + lane] = my_df;
+  }
+  f32x4 acc[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int col = 4 * lane + 256 * i;
+    acc[i] = dl0 * ld4(bw + col) + dl1 * ld4(bw + H + col);
+  }
+  for (int tk = 0; tk < TK; ++tk) {
+    const float d = __shfl(my_df, tk, 64);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc[i] += d * ld4(alpha + (size_t)tk * H + 4 * lane + 256 * i);
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int col = 4 * lane + 256 * i;
+    const f32x4 z = ld4(z4 + (size_t)row * H + col);
+    f32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      o[q] = acc[i][q] * gelu_grad_f(z[q]) * dropout_mul(st, clf_p, LAYER_PRE3, (uint32_t)(row * H + col + q));
+    st4(dz4 + (size_t)row * H + col, o);
+  }
+}
+
+// NODE / bypass parameter gradients.  blocks [0,TK): gate tk (+ its threshold); [TK,TK+2): bypass
+// row c (+ bias); block TK+2: leaf tables.  Deterministic loops over rows.
+__global__ __launch_bounds__(256) void node_param_kernel(const float* df, const float* dlog, const float* hh,
+                                                         const float* alpha, const float* fs, int B, int H, int trees,
+                                                         int depth, float node_p, const ufnd_step_state* st,
+                                                         float* g_gates, float* g_thresh, float* g_leaf, float* g_bw,
+                                                         float* g_bb) {
+  __shared__ float sh[4];
+  const int TK = trees * depth, blk = blockIdx.x;
+  if (blk < TK) {
+    float da[4] = {0, 0, 0, 0};
+    float part = 0;
+    int cnt = 0;
+    for (int c = threadIdx.x; c < H; c += 256, ++cnt) {
+      float s = 0;
+      for (int r = 0; r < B; ++r) s += df[(size_t)r * 64 + blk] * hh[(size_t)r * H + c];
+      da[cnt] = s;
+      part += alpha[(size_t)blk * H + c] * s;
+    }
+    part = wave_sum(part);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = part;
+    __syncthreads();
+    const float dotv = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    cnt = 0;
+    for (int c = threadIdx.x; c < H; c += 256, ++cnt)
+      g_gates[(size_t)blk * H + c] = alpha[(size_t)blk * H + c] * (da[cnt] - dotv);
+    if (threadIdx.x == 0) {
+      float s = 0;
+      for (int r = 0; r < B; ++r) s += df[(size_t)r * 64 + blk];
+      g_thresh[blk] = -s;
+    }
+  } else if (blk < TK + 2) {
+    const int c2 = blk - TK;
+    for (int c = threadIdx.x; c < H; c += 256) {
+      float s = 0;
+      for (int r = 0; r < B; ++r) s += dlog[r * 2 + c2] * hh[(size_t)r * H + c];
+      g_bw[(size_t)c2 * H + c] = s;
+    }
+    if (threadIdx.x == 0) {
+      float s = 0;
+      for (int r = 0; r < B; ++r) s += dlog[r * 2 + c2];
+      g_bb[c2] = s;
+    }
+  } else {
+    const int leaves = 1 << depth;
+    for (int idx = threadIdx.x; idx < trees * leaves * 2; idx += 256) {
+      const int c = idx & 1, l = (idx >> 1) % leaves, t = (idx >> 1) / leaves;
+      float s = 0;
+      for (int r = 0; r < B; ++r) {
+        float prob = 1.0f;
+        for (int k = 0; k < depth; ++k) {
+          const float sk = fs[(size_t)r * 64 + t * depth + k];
+          prob *= ((l >> k) & 1) ? sk : (1.0f - sk);
+        }
+        s += prob * dlog[r * 2 + c] / (float)trees *
+             dropout_mul(st, node_p, LAYER_TREE, (uint32_t)((r * trees + t) * 2 + c));
+      }
+      g_leaf[idx] = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- cross-entropy
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* logits, const int64_t* labels, int B,
+                                                         float* loss_rows, float* dlog, ufnd_step_state* st) {
+  __shared__ float sh[4];
+  float part = 0;
+  for (int r = threadIdx.x; r < B; r += 256) {
+    const float l0 = logits[r * 2], l1 = logits[r * 2 + 1], mx = fmaxf(l0, l1);
+    const float lse = mx + logf(__expf(l0 - mx) + __expf(l1 - mx));
+    const int y = (int)labels[r];
+    const float lr = lse - (y ? l1 : l0);
+    if (loss_rows) loss_rows[r] = lr;
+    part += lr;
+    if (dlog) {
+      dlog[r * 2] = (__expf(l0 - lse) - (y == 0 ? 1.f : 0.f)) / (float)B;
+      dlog[r * 2 + 1] = (__expf(l1 - lse) - (y == 1 ? 1.f : 0.f)) / (float)B;
+    }
+  }
+  part = wave_sum(part);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) st->loss = ((sh[0] + sh[1]) + (sh[2] + sh[3])) / (float)B;
+}
+
+int check_dims(const ufnd_dims* d, int B) {
+  UFND_REQUIRE(d, "dims is null");
+  UFND_REQUIRE(d->hidden == 256 || d->hidden == 512 || d->hidden == 1024, "hidden=%d: supported 256/512/1024", d->hidden);
+  UFND_REQUIRE(d->classes == 2, "classes=%d: only 2 supported", d->classes);
+  UFND_REQUIRE(d->depth >= 1 && d->depth <= 6 && d->trees >= 1 && d->trees * d->depth <= 64, "trees=%d depth=%d unsupported",
+               d->trees, d->depth);
+  UFND_REQUIRE(d->aux_dim >= 0 && d->aux_dim <= 4 && d->aux_dim % 2 == 0, "aux_dim=%d: supported 0, 2, 4", d->aux_dim);
+  UFND_REQUIRE(d->text_dim % 4 == 0 && d->audio_dim % 4 == 0 && d->visual_dim % 4 == 0 && d->temporal_dim % 4 == 0 &&
+                   d->gnn_dim % 4 == 0, "input feature dims must be multiples of 4");
+  UFND_REQUIRE(B >= 1 && B <= 65536, "B=%d out of range", B);
+  return UFND_OK;
+}
+
+#define NI_DISPATCH(H, KERNEL, GRID, BLOCK, STREAM, ...)                                    \
+  do {                                                                                      \
+    if ((H) == 256) hipLaunchKernelGGL((KERNEL<1>), GRID, BLOCK, 0, STREAM, __VA_ARGS__);   \
+    else if ((H) == 512) hipLaunchKernelGGL((KERNEL<2>), GRID, BLOCK, 0, STREAM, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<4>), GRID, BLOCK, 0, STREAM, __VA_ARGS__);              \
+  } while (0)
+
+#define TRY(x)                 \
+  do {                         \
+    int rc_ = (x);             \
+    if (rc_ != UFND_OK) return rc_; \
+  } while (0)
+
+}  // namespace
+
+// =============================================================================================
+extern "C" size_t ufnd_fusion_workspace_floats(const ufnd_dims* d, int B) {
+  if (!d || B < 1) return 0;
+  return carve_fusion(*d, B, nullptr).total;
+}
+extern "C" size_t ufnd_clf_workspace_floats(const ufnd_dims* d, int B) {
+  if (!d || B < 1) return 0;
+  return carve_clf(*d, B, nullptr).total;
+}
+extern "C" float* ufnd_clf_input_panel(const ufnd_dims* d, float* ws, int B, int* ld) {
+  if (!d || !ws) return nullptr;
+  ClfWs w = carve_clf(*d, B, ws);
+  if (ld) *ld = w.ldx;
+  return w.xin;
+}
+
+extern "C" int ufnd_fusion_forward(const ufnd_dims* d, const ufnd_fusion_params* p, const float* text,
+                                   const float* audio, const float* visual, const float* temporal, const float* gnn,
+                                   int B, int train, float* workspace, float* fused, int ld_fused, float* logits,
+                                   float* forensic, const ufnd_step_state* state, void* stream_) {
+  TRY(check_dims(d, B));
+  UFND_REQUIRE(p && text && audio && visual && temporal && workspace && fused && forensic && state, "fusion_forward: null argument");
+  UFND_REQUIRE(gnn, "fusion_forward: gnn_feat is required (fuse_mlp expects the 16*hidden concat, cross_modal_transformer.py:184-195)");
+  UFND_REQUIRE(ld_fused % 4 == 0 && ld_fused >= d->hidden && ufnd_aligned(fused, 16) && ufnd_aligned(workspace, 256),
+               "fusion_forward: fused/workspace alignment");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int H = d->hidden;
+  FusionWs w = carve_fusion(*d, B, workspace);
+  const float drop = train ? d->fusion_dropout : 0.0f;
+  const dim3 rows(ufnd_cdiv(B, 4)), blk(256);
+
+  // 1. five projections straight into their CAT slots                          (:147-150,184-187)
+  {
+    const float* xs[5] = {text, audio, visual, temporal, gnn};
+    const float* ws_[5] = {p->text_w, p->audio_w, p->visual_w, p->temporal_w, p->gnn_w};
+    const float* bs[5] = {p->text_b, p->audio_b, p->visual_b, p->temporal_b, p->gnn_b};
+    const int ks[5] = {d->text_dim, d->audio_dim, d->visual_dim, d->temporal_dim, d->gnn_dim};
+    const int slot[5] = {0, 1, 2, 3, 15};
+    NtProb pr[5];
+    for (int i = 0; i < 5; ++i)
+      pr[i] = NtProb{xs[i], ws_[i], bs[i], w.cat + (size_t)slot[i] * H, nullptr, B, H, ks[i], ks[i], ks[i], 16 * H, 0,
+                     0, 0.0f, 0, 1};
+    TRY(launch_nt(pr, 5, state, stream));
+  }
+  // 2. evidence scalars and the three evidence gates                                  (:153-164,48)
+  EvPtrs ev;
+  for (int b = 0; b < 3; ++b) { ev.w0[b] = p->ev0_w[b]; ev.b0[b] = p->ev0_b[b]; ev.w2[b] = p->ev2_w[b]; ev.b2[b] = p->ev2_b[b]; }
+  NI_DISPATCH(H, evidence_gate_kernel, rows, blk, stream, (const float*)w.cat, B, H, ev, w.evid, w.gate, forensic);
+  UFND_CHECK_LAUNCH();
+  // 3. stacked q/k/v projections: t -> [q_tv q_ta], v -> [k_tv v_tv q_vu], a -> [k_ta v_ta], u -> [k_vu v_vu]
+  {
+    const int src_slot[4] = {0, 2, 1, 3}, row0[4] = {0, 2, 5, 7}, nrows[4] = {2, 3, 2, 2};
+    NtProb pr[4];
+    for (int i = 0; i < 4; ++i)
+      pr[i] = NtProb{w.cat + (size_t)src_slot[i] * H, p->qkv_w + (size_t)row0[i] * H * H, p->qkv_b + (size_t)row0[i] * H,
+                     w.qkv + (size_t)row0[i] * H, nullptr, B, nrows[i] * H, H, 16 * H, H, 9 * H, 0, 0, 0.0f, 0, 1};
+    TRY(launch_nt(pr, 4, state, stream));
+  }
+  // 4. co-attention combine + pairwise features -> CAT slots 4..14                    (:44-54,172-178)
+  NI_DISPATCH(H, coattn_pairs_kernel, rows, blk, stream, w.cat, (const float*)w.qkv, (const float*)w.gate, B, H, w.s);
+  UFND_CHECK_LAUNCH();
+  // 5. fuse_mlp.0: (B,16H) x (2H,16H)^T, split-K then bias+GELU(+dropout)             (:122-124)
+  {
+    NtProb pr{w.cat, p->fuse0_w, nullptr, w.part1, nullptr, B, 2 * H, 16 * H, 16 * H, 16 * H, 2 * H, 0, 0, 0.0f, 0,
+              KSPLIT_FUSE0};
+    TRY(launch_nt(&pr, 1, state, stream));
+    const int n4 = B * 2 * H / 4;
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(ufnd_cdiv(n4, 256)), blk, 0, stream, (const float*)w.part1,
+                       KSPLIT_FUSE0, B, 2 * H, (const float*)p->fuse0_b, w.z1, w.h1, 1, drop, LAYER_FUSE0, state);
+    UFND_CHECK_LAUNCH();
+  }
+  // 6. fuse_mlp.3 + GELU(+dropout) -> fused                                           (:125-127)
+  {
+    NtProb pr{w.h1, p->fuse3_w, p->fuse3_b, fused, w.z2, B, H, 2 * H, 2 * H, 2 * H, ld_fused, H, 1, drop, LAYER_FUSE3, 1};
+    TRY(launch_nt(&pr, 1, state, stream));
+  }
+  // 7. aux head (unused by the trainer's loss, :198)
+  if (logits) {
+    hipLaunchKernelGGL(head2_fwd_kernel, rows, blk, 0, stream, (const float*)fused, ld_fused, (const float*)p->cls_w,
+                       (const float*)p->cls_b, logits, B, H);
+    UFND_CHECK_LAUNCH();
+  }
+  return UFND_OK;
+}
+
+extern "C" int ufnd_fusion_backward(const ufnd_dims* d, const ufnd_fusion_params* p, const ufnd_fusion_params* g,
+                                    const float* text, const float* audio, const float* visual, const float* temporal,
+                                    const float* gnn, int B, int train, float* workspace, const float* d_fused,
+                                    int ld_dfused, const float* d_logits, const ufnd_step_state* state, void* stream_) {
+  TRY(check_dims(d, B));
+  UFND_REQUIRE(p && g && text && audio && visual && temporal && gnn && workspace && state, "fusion_backward: null argument");
+  UFND_REQUIRE(d_fused || d_logits, "fusion_backward: no incoming gradient");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int H = d->hidden;
+  FusionWs w = carve_fusion(*d, B, workspace);
+  const float drop = train ? d->fusion_dropout : 0.0f;
+  const dim3 rows(ufnd_cdiv(B, 4)), blk(256);
+
+  // aux-head parameter grads (only when a gradient arrives at the aux logits)
+  if (d_logits) {
+    hipLaunchKernelGGL(head2_bwd_kernel, dim3(ufnd_cdiv(H, 256)), blk, 0, stream, d_logits, (const float*)w.z2, B, H,
+                       drop, LAYER_FUSE3, state, g->cls_w, g->cls_b);
+    UFND_CHECK_LAUNCH();
+  }
+  // dZ2 = (d_fused + d_logits Wc) * gelu'(Z2) * mask
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(ufnd_cdiv(B * H, 256)), blk, 0, stream, d_fused, ld_dfused, d_logits,
+                     (const float*)p->cls_w, (const float*)w.z2, w.dz2, B, H, drop, LAYER_FUSE3, state);
+  UFND_CHECK_LAUNCH();
+  // fuse_mlp.3: dW, db; dH1 -> dZ1 (epilogue applies gelu'(Z1) * mask)
+  {
+    TnProb t{w.dz2, w.h1, g->fuse3_w, g->fuse3_b, B, H, 2 * H, H, 2 * H, 2 * H};
+    TRY(launch_tn(&t, 1, stream));
+    NnProb n{w.dz2, p->fuse3_w, w.dz1, w.z1, nullptr, B, H, 2 * H, H, 2 * H, 2 * H, 2 * H, 0, drop, LAYER_FUSE0, 2 * H, 1};
+    TRY(launch_nn(&n, 1, state, stream));
+  }
+  // fuse_mlp.0: dW (the 33.5 MB gradient), db; dCAT partials
+  {
+    TnProb t{w.dz1, w.cat, g->fuse0_w, g->fuse0_b, B, 2 * H, 16 * H, 2 * H, 16 * H, 16 * H};
+    TRY(launch_tn(&t, 1, stream));
+    NnProb n{w.dz1, p->fuse0_w, w.dcatp, nullptr, nullptr, B, 2 * H, 16 * H, 2 * H, 16 * H, 16 * H, 0, 0, 0.0f, 0, 0,
+             NSPLIT_FUSE0};
+    TRY(launch_nn(&n, 1, state, stream));
+  }
+  // concat / pairwise / co-attention backward (row-wise)
+  NI_DISPATCH(H, coattn_pairs_bwd_kernel, rows, blk, stream, (const float*)w.dcatp, NSPLIT_FUSE0, (const float*)w.cat,
+              (const float*)w.qkv, (const float*)w.gate, (const float*)w.s, B, H, w.dtavu, w.dqkv, w.dg, w.dout);
+  UFND_CHECK_LAUNCH();
+  // evidence_proj parameter grads
+  {
+    EvPtrs ep;
+    EvGrads eg;
+    for (int b = 0; b < 3; ++b) {
+      ep.w0[b] = p->ev0_w[b]; ep.b0[b] = p->ev0_b[b]; ep.w2[b] = p->ev2_w[b]; ep.b2[b] = p->ev2_b[b];
+      eg.w0[b] = g->ev0_w[b]; eg.b0[b] = g->ev0_b[b]; eg.w2[b] = g->ev2_w[b]; eg.b2[b] = g->ev2_b[b];
+    }
+    hipLaunchKernelGGL(gate_param_kernel, dim3(3), dim3(H > 512 ? 512 : H), 0, stream, (const float*)w.evid,
+                       (const float*)w.dout, B, H, ep, eg);
+    UFND_CHECK_LAUNCH();
+  }
+  // stacked q/k/v: dW, db, and the extra gradient into t, v, a, u (accumulated in place)
+  {
+    const int src_slot[4] = {0, 2, 1, 3}, row0[4] = {0, 2, 5, 7}, nrows[4] = {2, 3, 2, 2};
+    TnProb t[4];
+    NnProb n[4];
+    for (int i = 0; i < 4; ++i) {
+      t[i] = TnProb{w.dqkv + (size_t)row0[i] * H, w.cat + (size_t)src_slot[i] * H, g->qkv_w + (size_t)row0[i] * H * H,
+                    g->qkv_b + (size_t)row0[i] * H, B, nrows[i] * H, H, 9 * H, 16 * H, H};
+      float* dst = w.dtavu + (size_t)src_slot[i] * B * H;  // dtavu order is [t a v u]
+      n[i] = NnProb{w.dqkv + (size_t)row0[i] * H, p->qkv_w + (size_t)row0[i] * H * H, dst, nullptr, dst, B, nrows[i] * H,
+                    H, 9 * H, H, H, 0, H, 0.0f, 0, 0, 1};
+    }
+    TRY(launch_tn(t, 4, stream));
+    TRY(launch_nn(n, 4, state, stream));
+  }
+  // projections: dW, db (inputs are data: no dX)
+  {
+    const float* xs[5] = {text, audio, visual, temporal, gnn};
+    float* gw[5] = {g->text_w, g->audio_w, g->visual_w, g->temporal_w, g->gnn_w};
+    float* gb[5] = {g->text_b, g->audio_b, g->visual_b, g->temporal_b, g->gnn_b};
+    const int ks[5] = {d->text_dim, d->audio_dim, d->visual_dim, d->temporal_dim, d->gnn_dim};
+    const float* dys[5] = {w.dtavu, w.dtavu + (size_t)B * H, w.dtavu + (size_t)2 * B * H, w.dtavu + (size_t)3 * B * H, w.dg};
+    TnProb t[5];
+    for (int i = 0; i < 5; ++i) t[i] = TnProb{dys[i], xs[i], gw[i], gb[i], B, H, ks[i], H, ks[i], ks[i]};
+    TRY(launch_tn(t, 5, stream));
+  }
+  return UFND_OK;
+}
+
+extern "C" int ufnd_classifier_forward(const ufnd_dims* d, const ufnd_clf_params* p, const float* fused, int ld_fused,
+                                       const float* aux, int B, int train, float* workspace, float* logits,
+                                       float* probs, const ufnd_step_state* state, void* stream_) {
+  TRY(check_dims(d, B));
+  UFND_REQUIRE(p && fused && workspace && logits && probs && state, "classifier_forward: null argument");
+  UFND_REQUIRE((d->aux_dim == 0) == (aux == nullptr), "classifier_forward: aux must be given iff aux_dim > 0 (pre.0 is %d wide)",
+               d->hidden + d->aux_dim);
+  UFND_REQUIRE(ufnd_aligned(workspace, 256), "classifier_forward: workspace alignment");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int H = d->hidden;
+  ClfWs w = carve_clf(*d, B, workspace);
+  const float drop = train ? d->clf_dropout : 0.0f;
+  const dim3 rows(ufnd_cdiv(B, 4)), blk(256);
+
+  hipLaunchKernelGGL(pack_xin_kernel, dim3(B), dim3(128), 0, stream, fused, ld_fused, aux, d->aux_dim, w.xin, w.ldx, B, H,
+                     fused != w.xin ? 1 : 0);
+  UFND_CHECK_LAUNCH();
+  {  // pre.0 / pre.3 + GELU(+dropout)                                    deep_truth_classifier.py:121-128
+    NtProb a{w.xin, p->pre0_w, p->pre0_b, w.h3, w.z3, B, H, H + d->aux_dim, w.ldx, H + d->aux_dim, H, H, 1, drop, LAYER_PRE0, 1};
+    TRY(launch_nt(&a, 1, state, stream));
+    NtProb b{w.h3, p->pre3_w, p->pre3_b, w.hh, w.z4, B, H, H, H, H, H, H, 1, drop, LAYER_PRE3, 1};
+    TRY(launch_nt(&b, 1, state, stream));
+  }
+  hipLaunchKernelGGL(alpha_kernel, dim3(d->trees * d->depth), blk, 0, stream, (const float*)p->gates, w.alpha, H);
+  UFND_CHECK_LAUNCH();
+  NI_DISPATCH(H, node_head_kernel, rows, blk, stream, (const float*)w.hh, (const float*)w.alpha, (const float*)p->thresh,
+              (const float*)p->leaf, (const float*)p->tau, (const float*)p->bypass_w, (const float*)p->bypass_b,
+              (const float*)p->temperature, B, H, d->trees, d->depth, train ? d->node_dropout : 0.0f, state, w.fs, logits,
+              probs);
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}
+
+extern "C" int ufnd_classifier_backward(const ufnd_dims* d, const ufnd_clf_params* p, const ufnd_clf_params* g, int B,
+                                        int train, float* workspace, const float* d_logits, float* d_fused,
+                                        int ld_dfused, const ufnd_step_state* state, void* stream_) {
+  TRY(check_dims(d, B));
+  UFND_REQUIRE(p && g && workspace && d_logits && d_fused && state, "classifier_backward: null argument");
+  UFND_REQUIRE(ld_dfused % 4 == 0 && ufnd_aligned(d_fused, 16), "classifier_backward: d_fused alignment");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int H = d->hidden;
+  ClfWs w = carve_clf(*d, B, workspace);
+  const float drop = train ? d->clf_dropout : 0.0f, ndrop = train ? d->node_dropout : 0.0f;
+  const dim3 rows(ufnd_cdiv(B, 4)), blk(256);
+
+  NI_DISPATCH(H, node_bwd_kernel, rows, blk, stream, d_logits, (const float*)w.fs, (const float*)w.alpha,
+              (const float*)p->leaf, (const float*)p->tau, (const float*)p->bypass_w, (const float*)w.z4, B, H, d->trees,
+              d->depth, ndrop, drop, state, w.df, w.dz4);
+  UFND_CHECK_LAUNCH();
+  hipLaunchKernelGGL(node_param_kernel, dim3(d->trees * d->depth + 3), blk, 0, stream, (const float*)w.df, d_logits,
+                     (const float*)w.hh, (const float*)w.alpha, (const float*)w.fs, B, H, d->trees, d->depth, ndrop, state,
+                     g->gates, g->thresh, g->leaf, g->bypass_w, g->bypass_b);
+  UFND_CHECK_LAUNCH();
+  {  // pre.3
+    TnProb t{w.dz4, w.h3, g->pre3_w, g->pre3_b, B, H, H, H, H, H};
+    TRY(launch_tn(&t, 1, stream));
+    NnProb n{w.dz4, p->pre3_w, w.dz3, w.z3, nullptr, B, H, H, H, H, H, H, 0, drop, LAYER_PRE0, H, 1};
+    TRY(launch_nn(&n, 1, state, stream));
+  }
+  {  // pre.0: dW over the full (hidden + aux) width, dX only over the fused columns
+    TnProb t{w.dz3, w.xin, g->pre0_w, g->pre0_b, B, H, H + d->aux_dim, H, w.ldx, H + d->aux_dim};
+    TRY(launch_tn(&t, 1, stream));
+    NnProb n{w.dz3, p->pre0_w, d_fused, nullptr, nullptr, B, H, H, H, H + d->aux_dim, ld_dfused, 0, 0, 0.0f, 0, 0, 1};
+    TRY(launch_nn(&n, 1, state, stream));
+  }
+  return UFND_OK;
+}
+
+extern "C" int ufnd_softmax_ce(const float* logits, const int64_t* labels, int B, float* loss_rows, float* d_logits,
+                               ufnd_step_state* state, void* stream_) {
+  UFND_REQUIRE(logits && labels && state && B >= 1, "softmax_ce: null argument");
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream_, logits, labels, B, loss_rows, d_logits,
+                     state);
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}
