@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py -- train-step samples/s of the text+vision fusion hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one synthetic FakeSV batch (BASELINE.json configs[1]:
+full model, batch 32 per GPU, seq_len 128, one 224x224 frame), inputs resident in HBM:
+  BERT-base text encoder fwd (bf16 MFMA) + ViT-B/32 visual encoder fwd (bf16 MFMA) -> pooled
+  features -> CrossModalTransformer + DeepTruthClassifier fwd (train-mode dropout) -> CE ->
+  backward -> [RCCL all-reduce] -> clip_grad_norm_(5) -> AdamW.   (encoders frozen, as in the
+  reference; nothing is cached or skipped inside the timed region.)
+Prints ONE JSON line (rank 0) with the contract's fields plus `roofline` (the bf16 GEMM kernel,
+timed with HIP events on its stream) and `cpu_baseline` (the oracle's same step on host cores,
+bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+SEQ_LEN, IMAGE, FRAMES = 128, 224, 1
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def gemm_flops_per_step(B: int) -> tuple[float, int]:
+    """Algorithmic FLOPs and launch count of ufnd_gemm_bf16 in one step."""
+    H, I3 = 768, 3072
+    per_tok = 2.0 * (H * 3 * H + H * H + 2 * H * I3)           # QKV + out + FFN1 + FFN2
+    text = 12 * (B * SEQ_LEN) * per_tok
+    n = B * FRAMES
+    vis = 2.0 * (n * 49) * 3072 * H + 12 * (n * 50) * per_tok + 2.0 * n * H * 512
+    return text + vis, 12 * 4 + 1 + 12 * 4 + 1
+
+
+def make_batches(B: int, n: int, seed: int, dev: torch.device):
+    """Synthetic FakeSV-shaped raw batches, already in HBM."""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n):
+        ids = torch.randint(0, 30522, (B, SEQ_LEN), generator=g)
+        ids[:, 0] = 101
+        lens = torch.randint(16, SEQ_LEN + 1, (B,), generator=g)
+        a = torch.randn(B, 128, generator=g)
+        out.append({"input_ids": ids.to(dev), "attention_mask": (torch.arange(SEQ_LEN)[None] < lens[:, None]).to(torch.int32).to(dev),
+                    "frames": torch.randn(B, FRAMES, 3, IMAGE, IMAGE, generator=g).to(dev),
+                    "audio_features": (a / a.norm(dim=1, keepdim=True)).to(dev),
+                    "temporal_features": torch.randn(B, 256, generator=g).to(dev),
+                    "gnn_feat": torch.randn(B, 128, generator=g).to(dev), "aux": torch.rand(B, 2, generator=g).to(dev),
+                    "label": torch.randint(0, 2, (B,), generator=g).to(dev)})
+    return out
+
+
+def cpu_baseline(B: int, budget_s: float = 18.0):
+    """The oracle's restatement of the same step on the host cores (kind 'port')."""
+    from oracle import encoders_ref as E
+    from oracle import tier_a as O
+    wt = E.seeded_weights(E.bert_shapes(), 1)
+    wv = E.seeded_weights(E.vit_shapes(), 2)
+    fus, clf = O.seeded_params(3)
+    opt = O.AdamWState()
+    ids, mask = E.synthetic_tokens(4, B, SEQ_LEN)
+    frames = E.synthetic_frames(5, B, FRAMES)
+    batch = O.seeded_batch(6, B)
+
+    def step():
+        with torch.no_grad():
+            batch["text_features"] = E.text_features(wt, ids, mask)
+            batch["visual_features"] = E.visual_features(wv, frames)
+        O.train_step(fus, clf, batch, opt, grad_clip=5.0, train=True, dropout=0.1)
+    step()                                   # warm-up
+    n, t0 = 0, time.perf_counter()
+    while n < 8 and (n == 0 or time.perf_counter() - t0 < budget_s):
+        step()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(n * B / dt, 3), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} step(s) of the same workload (B={B}, L={SEQ_LEN}, {FRAMES}x{IMAGE}^2 frame), "
+                      f"{dt / n * 1e3:.0f} ms/step, host has {os.cpu_count()} cpus"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1]: 32)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (MI355X); there is no CPU path to time as the product")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    if args.gpus != world and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: using {world}", file=sys.stderr)
+
+    from ultrafnd_git_amd.encoders import BertTextEncoder, ClipVisualEncoder
+    from ultrafnd_git_amd.trainer import ForensicTrainer, TrainConfig, synthetic_cache
+
+    B = args.batch
+    torch.manual_seed(42)
+    tenc = BertTextEncoder().to(dev)            # BERT-base geometry, random init (no checkpoints offline)
+    venc = ClipVisualEncoder().to(dev)          # CLIP ViT-B/32 geometry, random init
+    cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir="/tmp/ufnd_bench", batch_size=B, device=str(dev),
+                      use_graph=not args.no_graph, encode_inline=True, seed=42)
+    tr = ForensicTrainer(cfg, cache=synthetic_cache(64, seed=1), text_encoder=tenc, visual_encoder=venc)
+    tr.fusion.train()
+    tr.clf.train()
+    batches = make_batches(B, 4, 42 + 2 + 1000 * rank, dev)
+
+    def run(n):
+        """Software-pipelined steps: the all-reduce of step i overlaps the encoders of step i+1."""
+        tr.prefetch_features(batches[0])
+        for i in range(n):
+            tr.train_step_pipelined(batches[i % 4], batches[(i + 1) % 4] if i + 1 < n else None)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    run(args.warmup)
+    fence()
+    t0 = time.perf_counter()
+    run(args.steps)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(tr.optim.state.read().loss)
+
+    # ---- roofline of the dominant kernel (bf16 GEMM): HIP events around every launch, instrumented pass
+    roof = None
+    if rank == 0:
+        gem_ms, launches = tr.measure_gemm_time(batches[0], steps=3)
+        flops, n_launch = gemm_flops_per_step(B)
+        assert launches == n_launch, (launches, n_launch)
+        achieved = flops / (gem_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                "launches_per_step": n_launch, "avg_launch_us": round(gem_ms * 1e3 / n_launch, 2),
+                "gemm_ms_per_step": round(gem_ms, 4), "flops_per_launch_avg": flops / n_launch}
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(B)
+    if rank == 0:
+        value = world * B * args.steps / dt
+        print(json.dumps({
+            "metric": "train-step samples/sec (FakeSV batch, seq128+224^2)", "value": round(value, 2), "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: full Ultrafnd step (BERT-base L=128 fwd + ViT-B/32 224^2 fwd, frozen; "
+                                   "fusion+classifier fwd/bwd, clip, AdamW)", "per_gpu_batch": B, "global_batch": world * B,
+                       "seq_len": SEQ_LEN, "frames": FRAMES, "image": IMAGE, "parallelism": f"dp{world}",
+                       "encoder_dtype": "bf16 operands / fp32 accumulate", "head_dtype": "fp32", "hip_graph": not args.no_graph,
+                       "weights": "random init of the named architectures"},
+            "final_loss": final_loss, "roofline": roof, "cpu_baseline": cpu}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

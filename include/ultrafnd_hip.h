@@ -173,6 +173,67 @@ int ufnd_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_
                     const ufnd_step_state* state, void* stream);
 int ufnd_step_advance(ufnd_step_state* state, void* stream);
 
+/* ====================================================================================
+ * Tier B -- the frozen, forward-only encoders that produce `text` and `visual`
+ * (SURVEY.md 8 rows a10/a11).  bf16 operands on v_mfma_f32_16x16x32_bf16, fp32
+ * accumulate, fp32 residual stream, fp32 LayerNorm/softmax statistics.
+ * The arithmetic these replace is third-party: transformers' BertModel (called at
+ * src/core_blocks/text_blocks.py:79) and CLIPVisionModel (geometry pointer
+ * configs/model_configs/semantic.yaml:2); the pooling is the reference's own
+ * (text_blocks.py:82-101,126-128).
+ * ================================================================================== */
+#define UFND_ACT_NONE 0
+#define UFND_ACT_GELU 1       /* exact erf GELU (BERT intermediate) */
+#define UFND_ACT_QUICK_GELU 2 /* x * sigmoid(1.702 x) (CLIP MLP) */
+
+/* fp32 -> bf16 (round to nearest even); used once per weight tensor. */
+int ufnd_cast_bf16(const float* src, void* dst_bf16, size_t n, void* stream);
+
+/* out = act(A W^T + bias) + residual -- every nn.Linear of both encoders.
+ *   A (M,K) bf16 row stride lda; W (N,K) bf16 row stride ldw (nn.Linear layout);
+ *   bias fp32 (N) or NULL; residual fp32 (M,N) row stride ldr or NULL (added after act);
+ *   out_bf16 (M,N) row stride ldo and/or out_f32 (M,N) row stride ldf (either may be NULL).
+ *   K % 64 == 0, N % 64 == 0, strides multiples of 8, pointers 16-byte aligned. */
+int ufnd_gemm_bf16(const void* A, const void* W, const float* bias, const float* residual, void* out_bf16,
+                   float* out_f32, int M, int N, int K, int lda, int ldw, int ldr, int ldo, int ldf, int act,
+                   void* stream);
+
+/* y = LayerNorm(x) * gamma + beta over the last dim (H % 256 == 0, H <= 1024).
+ *   x fp32 rows with stride ldx; outputs (M,H) contiguous: bf16 (next GEMM's operand) and/or
+ *   fp32 (the residual stream). */
+int ufnd_layernorm(const float* x, int ldx, const float* gamma, const float* beta, void* out_bf16, float* out_f32,
+                   int M, int H, float eps, void* stream);
+
+/* softmax(Q K^T / sqrt(d) + mask) V for every (batch, head); d = 64.
+ *   qkv (B*L, 3*heads*64) bf16 = [Q | K | V] per token (the fused QKV projection's output);
+ *   key_mask (B,L) int32, 1 = attend, 0 = masked (HF's additive finfo.min), or NULL;
+ *   ctx (B*L, heads*64) bf16. */
+int ufnd_attention_bf16(const void* qkv, const int32_t* key_mask, void* ctx, int B, int L, int heads,
+                        void* stream);
+
+/* BertEmbeddings: LayerNorm(word[ids] + position[0..L) + token_type[0]).  Tables fp32.
+ *   ids (B,L) int64 in [0,vocab).  Outputs (B*L,H): bf16 and fp32. */
+int ufnd_bert_embed(const int64_t* ids, const float* word, const float* pos, const float* type0, const float* gamma,
+                    const float* beta, void* x_bf16, float* x_f32, int B, int L, int H, int vocab, float eps,
+                    void* stream);
+
+/* BERTContextEncoder.encode pooling (text_blocks.py:82-86,100): masked mean over tokens
+ * (denominator clamp_min 1e-6) then v / (||v|| + 1e-9).  hidden (B,L,H) fp32, mask (B,L) int32. */
+int ufnd_masked_meanpool_l2(const float* hidden, const int32_t* mask, float* out, int B, int L, int H,
+                            void* stream);
+
+/* CLIP patch embedding as an im2col-free GEMM operand: frames (N,3,S,S) fp32 ->
+ * patches (N*(S/P)^2, 3*P*P) bf16 in the conv weight's (c,ky,kx) order. */
+int ufnd_vit_patchify(const float* frames, void* patches_bf16, int N, int image, int patch, void* stream);
+
+/* tokens = pre_layrnorm([class_embedding ; patch_emb] + position_embedding) -> x_f32 (N, P+1, H). */
+int ufnd_vit_assemble(const float* patch_emb, const float* cls, const float* pos, const float* gamma,
+                      const float* beta, float* x_f32, int N, int P, int H, float eps, void* stream);
+
+/* per-frame e / (||e|| + 1e-9); then, for F > 1, mean over the F frames of a sample and
+ * L2-normalise again (text_blocks.py:126-128 idiom).  e (B*F, D) fp32 -> out (B, D). */
+int ufnd_l2norm_frames(const float* e, float* out, int B, int F, int D, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,221 @@
+"""GPU parity (through the C ABI): bf16 encoder kernels vs torch references and vs the Tier-B oracle /
+third-party golden outputs (tests/golden/tier_b.npz).
+
+Tolerances.  Kernels are compared with an fp32 torch evaluation of the SAME bf16-rounded operands, so
+only accumulation order and the output rounding differ: fp32 outputs 2e-3 * scale, bf16 outputs one
+bf16 ulp (2^-8 relative) on top.  Encoder features (unit-norm vectors, rms entry 0.036 / 0.044) are
+compared with the all-fp32 oracle / third-party outputs: 4e-3 max-abs (bf16 operand rounding through
+2..12 layers); the end-to-end LOGIT error that north_star bounds by 1e-3 is reported by
+test_end_to_end_logit_error.
+"""
+import ctypes as C
+import json
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.helpers import load_npz
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _lib():
+    from ultrafnd_git_amd import _lib as L
+    return L
+
+
+def _gemm(A, W, bias=None, residual=None, act=0, want_bf16=True, want_f32=True):
+    L = _lib()
+    M, K = A.shape
+    N = W.shape[0]
+    ob = torch.empty(M, N, dtype=torch.bfloat16, device=DEV) if want_bf16 else None
+    of = torch.empty(M, N, dtype=torch.float32, device=DEV) if want_f32 else None
+    L.check(L.lib().ufnd_gemm_bf16(A.data_ptr(), W.data_ptr(), L.ptr(bias), L.ptr(residual), L.ptr(ob), L.ptr(of), M, N, K,
+                                   A.stride(0), W.stride(0), N if residual is not None else 0, N, N, act,
+                                   L.stream_ptr(A.device)), "gemm")
+    torch.cuda.synchronize()
+    return ob, of
+
+
+@pytest.mark.parametrize("M,N,K,act,use_bias,use_res", [
+    (4096, 2304, 768, 0, True, False),     # BERT QKV (wide tile)
+    (4096, 3072, 768, 1, True, False),     # FFN1 + GELU
+    (4096, 768, 3072, 0, True, True),      # FFN2 + residual (narrow tile)
+    (1600, 3072, 768, 2, True, False),     # ViT fc1 + quick_gelu, ragged M
+    (130, 512, 768, 0, False, False),      # projection, tiny ragged M
+    (1, 64, 64, 0, True, True),            # minimum sizes
+    (257, 128, 192, 0, True, False),
+])
+def test_gemm_bf16(M, N, K, act, use_bias, use_res):
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g)).to(DEV).bfloat16()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV).bfloat16()
+    bias = torch.randn(N, generator=g).to(DEV) if use_bias else None
+    res = torch.randn(M, N, generator=g).to(DEV) if use_res else None
+    ob, of = _gemm(A, W, bias, res, act)
+    ref = A.float() @ W.float().t()
+    if use_bias:
+        ref = ref + bias
+    if act == 1:
+        ref = F.gelu(ref)
+    elif act == 2:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    if use_res:
+        ref = ref + res
+    scale = ref.abs().max().item()
+    e32 = (of - ref).abs().max().item()
+    e16 = (ob.float() - ref).abs().max().item()
+    print(f"gemm {M}x{N}x{K} act={act}: f32 err {e32:.2e} bf16 err {e16:.2e} scale {scale:.2f}")
+    assert e32 <= 2e-3 * max(scale, 1.0), e32
+    assert e16 <= (2e-3 + 2 ** -8) * max(scale, 1.0), e16
+
+
+def test_gemm_rejects_bad_shapes():
+    L = _lib()
+    A = torch.zeros(8, 96, dtype=torch.bfloat16, device=DEV)
+    W = torch.zeros(64, 96, dtype=torch.bfloat16, device=DEV)
+    o = torch.zeros(8, 64, device=DEV)
+    rc = L.lib().ufnd_gemm_bf16(A.data_ptr(), W.data_ptr(), None, None, None, o.data_ptr(), 8, 64, 96, 96, 96, 0, 0, 64, 0, None)
+    assert rc == 1 and b"K%64" in L.lib().ufnd_last_error()
+
+
+@pytest.mark.parametrize("M,H,eps", [(515, 768, 1e-12), (50, 768, 1e-5), (7, 512, 1e-5)])
+def test_layernorm(M, H, eps):
+    L = _lib()
+    g = torch.Generator().manual_seed(M)
+    x = (torch.randn(M, H, generator=g) * 3 + 0.5).to(DEV)
+    gm, bt = torch.randn(H, generator=g).to(DEV), torch.randn(H, generator=g).to(DEV)
+    ob = torch.empty(M, H, dtype=torch.bfloat16, device=DEV)
+    of = torch.empty(M, H, device=DEV)
+    L.check(L.lib().ufnd_layernorm(x.data_ptr(), H, gm.data_ptr(), bt.data_ptr(), ob.data_ptr(), of.data_ptr(), M, H, eps,
+                                   L.stream_ptr(x.device)), "ln")
+    ref = F.layer_norm(x, (H,), gm, bt, eps)
+    assert (of - ref).abs().max().item() <= 2e-5
+    assert (ob.float() - ref).abs().max().item() <= 2 ** -8 * ref.abs().max().item() + 2e-5
+
+
+@pytest.mark.parametrize("B,Lq,masked", [(3, 128, True), (2, 50, False), (2, 40, True), (2, 512, True), (1, 130, True)])
+def test_attention(B, Lq, masked):
+    L = _lib()
+    heads, H = 12, 768
+    g = torch.Generator().manual_seed(Lq)
+    qkv = (torch.randn(B * Lq, 3 * H, generator=g) * 1.5).to(DEV).bfloat16()
+    mask = None
+    if masked:
+        lens = torch.randint(1, Lq + 1, (B,), generator=g)
+        mask = (torch.arange(Lq)[None] < lens[:, None]).to(torch.int32)
+        if B > 1:
+            mask[1] = 0                                   # fully masked row: HF semantics = uniform average
+        mask = mask.to(DEV)
+    ctx = torch.empty(B * Lq, H, dtype=torch.bfloat16, device=DEV)
+    L.check(L.lib().ufnd_attention_bf16(qkv.data_ptr(), L.ptr(mask), ctx.data_ptr(), B, Lq, heads, L.stream_ptr(qkv.device)), "attn")
+    torch.cuda.synchronize()
+    q, k, v = [t.view(B, Lq, heads, 64).transpose(1, 2) for t in qkv.float().split(H, dim=1)]
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    if mask is not None:
+        s = s + (1.0 - mask[:, None, None, :].float()) * torch.finfo(torch.float32).min
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * Lq, H)
+    err = (ctx.float() - ref).abs().max().item()
+    print(f"attention B={B} L={Lq} masked={masked}: max-abs-err {err:.3e} (|ref| max {ref.abs().max().item():.2f})")
+    assert torch.isfinite(ctx.float()).all()
+    assert err <= 3e-2, err          # P and the output are rounded to bf16 (2^-8 relative each); |V| <= ~7
+
+
+@pytest.mark.parametrize("tag", ["bert2_L128", "bert2_L512", "bert2_L40"])
+def test_text_features_match_third_party(tag):
+    from oracle import encoders_ref as E
+    from ultrafnd_git_amd.encoders import BertTextEncoder
+    z = load_npz("tier_b.npz")
+    meta = json.loads(str(z[f"{tag}/meta"]))
+    w = E.seeded_weights(E.bert_shapes(layers=meta["layers"], vocab=meta["vocab"]), meta["weight_seed"])
+    enc = BertTextEncoder(layers=meta["layers"], vocab_size=meta["vocab"])
+    enc.load_state_dict(w)
+    enc = enc.to(DEV)
+    ids, mask = torch.from_numpy(z[f"{tag}/ids"]), torch.from_numpy(z[f"{tag}/mask"])
+    hid = enc.last_hidden_state(ids, mask)
+    n0 = int(mask[0].sum())
+    eh = np.abs(hid[0, :n0].cpu().numpy() - z[f"{tag}/hidden_row0"]).max()
+    feat = enc(ids, mask).cpu().numpy()
+    ef = np.abs(feat - z[f"{tag}/features"]).max()
+    print(f"{tag}: hidden max-abs-err {eh:.3e}, feature max-abs-err {ef:.3e}")
+    assert ef <= 4e-3 and eh <= 0.15, (ef, eh)
+
+
+@pytest.mark.parametrize("tag", ["vit2_F1", "vit2_F4"])
+def test_visual_features_match_third_party(tag):
+    from oracle import encoders_ref as E
+    from ultrafnd_git_amd.encoders import ClipVisualEncoder
+    z = load_npz("tier_b.npz")
+    meta = json.loads(str(z[f"{tag}/meta"]))
+    w = E.seeded_weights(E.vit_shapes(layers=meta["layers"]), meta["weight_seed"])
+    enc = ClipVisualEncoder(layers=meta["layers"])
+    enc.load_state_dict(w)
+    enc = enc.to(DEV)
+    frames = E.synthetic_frames(meta["frame_seed"], meta["B"], meta["F"])
+    feat = enc(frames).cpu().numpy()
+    ef = np.abs(feat - z[f"{tag}/features"]).max()
+    ee = np.abs(enc.image_embeds(frames.reshape(-1, 3, 224, 224)).cpu().numpy() - z[f"{tag}/image_embeds"]).max()
+    print(f"{tag}: feature max-abs-err {ef:.3e}, image_embeds max-abs-err {ee:.3e}")
+    assert ef <= 4e-3, ef
+
+
+def test_full_depth_encoders_vs_oracle():
+    """12-layer BERT-base / ViT-B/32 geometry (small vocab to keep the CPU oracle quick)."""
+    from oracle import encoders_ref as E
+    from ultrafnd_git_amd.encoders import BertTextEncoder, ClipVisualEncoder
+    w = E.seeded_weights(E.bert_shapes(layers=12, vocab=1000), 41)
+    enc = BertTextEncoder(layers=12, vocab_size=1000)
+    enc.load_state_dict(w)
+    enc = enc.to(DEV)
+    ids, mask = E.synthetic_tokens(141, 4, 128, vocab=1000)
+    et = (enc(ids, mask).cpu() - E.text_features(w, ids, mask)).abs().max().item()
+    w = E.seeded_weights(E.vit_shapes(layers=12), 42)
+    venc = ClipVisualEncoder(layers=12)
+    venc.load_state_dict(w)
+    venc = venc.to(DEV)
+    fr = E.synthetic_frames(142, 2, 1)
+    ev = (venc(fr).cpu() - E.visual_features(w, fr)).abs().max().item()
+    print(f"12-layer feature max-abs-err: text {et:.3e} visual {ev:.3e}")
+    assert et <= 6e-3 and ev <= 6e-3, (et, ev)
+
+
+def test_end_to_end_logit_error():
+    """north_star's bound: logits of the whole GPU path (bf16 encoders -> fp32 fusion head) within 1e-3 of
+    the all-fp32 CPU path on the same synthetic FakeSV batch and weights."""
+    from oracle import encoders_ref as E
+    from oracle import tier_a as O
+    from ultrafnd_git_amd.classifier import DeepTruthClassifier
+    from ultrafnd_git_amd.encoders import BertTextEncoder, ClipVisualEncoder
+    from ultrafnd_git_amd.fusion import CrossModalTransformer
+    B, Lq = 4, 128
+    wt = E.seeded_weights(E.bert_shapes(layers=12, vocab=1000), 41)
+    wv = E.seeded_weights(E.vit_shapes(layers=12), 42)
+    ids, mask = E.synthetic_tokens(7, B, Lq, vocab=1000)
+    frames = E.synthetic_frames(8, B, 1)
+    batch = O.seeded_batch(9, B)
+    fus_sd, clf_sd = O.seeded_params(1234)
+    # CPU fp32 reference path
+    ref_b = dict(batch)
+    ref_b["text_features"] = E.text_features(wt, ids, mask)
+    ref_b["visual_features"] = E.visual_features(wv, frames)
+    ref = O.forward_batch(fus_sd, clf_sd, ref_b)
+    # GPU path
+    tenc, venc = BertTextEncoder(layers=12, vocab_size=1000), ClipVisualEncoder(layers=12)
+    tenc.load_state_dict(wt); venc.load_state_dict(wv)
+    tenc, venc = tenc.to(DEV), venc.to(DEV)
+    fusion, clf = CrossModalTransformer(), DeepTruthClassifier()
+    fusion.load_state_dict(fus_sd); clf.load_state_dict(clf_sd)
+    fusion, clf = fusion.to(DEV).eval(), clf.to(DEV).eval()
+    feats = {k: batch[k].to(DEV) for k in ("audio_features", "temporal_features", "gnn_feat")}
+    feats["text_features"] = tenc(ids, mask)
+    feats["visual_features"] = venc(frames)
+    with torch.no_grad():
+        fo = fusion(feats)
+        co = clf(fo["fused"], batch["aux"].to(DEV))
+    err = (co["logits"].cpu() - ref["logits"]).abs().max().item()
+    perr = (co["probs"].cpu() - ref["probs"]).abs().max().item()
+    print(f"end-to-end logits max-abs-err {err:.3e} (probs {perr:.3e}); |logits| max {ref['logits'].abs().max().item():.3f}")
+    assert err <= 1e-3, err

@@ -1,0 +1,126 @@
+"""GPU: the fused train step behind the reference's trainer API (eager, hipGraph replay, pipelined)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import assert_digest_close, load_npz
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _trainer(tmp_path, B, use_graph, n=64, **kw):
+    from ultrafnd_git_amd.trainer import ForensicTrainer, TrainConfig, synthetic_cache
+    cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir=str(tmp_path), batch_size=B, device=DEV,
+                      use_graph=use_graph, **kw)
+    return ForensicTrainer(cfg, cache=synthetic_cache(n, seed=3))
+
+
+def _golden_batch(z):
+    b = {k: torch.from_numpy(z[f"in/{k}"]).to(DEV) for k in
+         ("text_features", "audio_features", "visual_features", "temporal_features", "gnn_feat", "aux", "label")}
+    return b
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_fused_step_matches_reference(tmp_path, use_graph):
+    """ForensicTrainer.train_step x3 on the B=32 golden batch == the reference's 3 optimizer steps."""
+    from oracle import tier_a as O
+    z = load_npz("tier_a_B32.npz")
+    tr = _trainer(tmp_path, 32, use_graph)
+    fus_sd, clf_sd = O.seeded_params(int(z["param_seed"]))
+    tr.fusion.load_state_dict(fus_sd)
+    tr.clf.load_state_dict(clf_sd)
+    tr.fusion.dropout = tr.clf.dropout = tr.clf.node_dropout = 0.0
+    tr.fusion.train(); tr.clf.train()
+    batch = _golden_batch(z)
+    for step in (1, 2, 3):
+        out = tr.train_step(batch)
+        loss = float(out["loss"].cpu())
+        assert abs(loss - float(z[f"step{step}/loss"])) <= 5e-5, (step, loss)
+        assert np.abs(out["logits"].cpu().numpy() - z[f"step{step}/logits"]).max() <= 1e-4
+    for k, p in list(("fusion." + k, p) for k, p in tr.fusion.named_parameters()) + \
+            list(("clf." + k, p) for k, p in tr.clf.named_parameters()):
+        if p.dim():
+            assert_digest_close(z, f"param_step3/{k}", p.detach(), rtol=2e-5, atol=2e-7)
+
+
+def test_graph_replay_is_bit_identical_to_eager(tmp_path):
+    res = []
+    for use_graph in (False, True):
+        torch.manual_seed(5)
+        tr = _trainer(tmp_path, 16, use_graph)
+        tr.fusion.train(); tr.clf.train()
+        it = iter(tr.train_loader)
+        for _ in range(2):
+            out = tr.train_step(next(it))
+        res.append((out["logits"].clone(), tr.arena.data.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+def test_fit_and_test_contract(tmp_path, capsys):
+    """fit() / test() keep the reference's contract: returns, printed lines, best.pt keys."""
+    from ultrafnd_git_amd.trainer import ForensicTrainer, TrainConfig, synthetic_cache
+    cache = synthetic_cache(200, seed=9)
+    # make the labels learnable from the text features so AUC moves
+    w = np.random.default_rng(0).standard_normal(768).astype(np.float32)
+    cache["labels"] = (cache["text"] @ w > 0).astype(np.int64)
+    cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir=str(tmp_path), batch_size=16, epochs=4, device=DEV, lr=1e-3)
+    tr = ForensicTrainer(cfg, cache=cache)
+    l0, _ = tr._epoch_loop(tr.val_loader, "val")
+    best = tr.fit()
+    res = tr.test()
+    assert set(res) == {"test_loss", "test_acc", "test_auc", "test_precision", "test_recall", "test_f1", "test_cmcs", "test_dfdr"}
+    assert 0.5 < best <= 1.0 and res["test_auc"] > 0.6, (best, res)
+    ck = torch.load(tr.ckpt_path, map_location="cpu", weights_only=True)
+    assert set(ck) == {"fusion", "clf", "gnn", "cfg"} and ck["gnn"] is None
+    assert "semantic.text_proj.0.weight" in ck["fusion"] and "node.trees.5.thresh.3" in ck["clf"]
+    out = capsys.readouterr().out
+    assert "[Epoch 01] train_loss=" in out and "[val]" in out and "[Test] loss=" in out
+    o = tr._forward_batch(next(iter(tr.test_loader)), "test")
+    assert set(o) == {"logits", "probs", "y", "forensic"} and set(o["forensic"]) == {"emotion_intensity", "semantic_conflict", "temporal_delay"}
+    assert abs(tr.scheduler.get_last_lr()[0] - 1e-3 * 0.7 ** (tr.scheduler.last_epoch // 3)) < 1e-12
+
+
+def test_ragged_last_batch_and_tiny_batches(tmp_path):
+    tr = _trainer(tmp_path, 24, True, n=50)       # train split 35 -> batches of 24 and 11
+    tr.fusion.train(); tr.clf.train()
+    sizes = [int(b["label"].shape[0]) for b in tr.train_loader]
+    assert sizes == [24, 11]
+    loss, m = tr._epoch_loop(tr.train_loader, "train")
+    assert np.isfinite(loss) and 0.0 <= m["accuracy"] <= 1.0
+    tr1 = _trainer(tmp_path, 1, False, n=20)
+    loss, _ = tr1._epoch_loop(tr1.train_loader, "train")
+    assert np.isfinite(loss)
+
+
+def test_pipelined_step_equals_plain_step(tmp_path):
+    """encode_inline: all-reduce/encoder overlap schedule changes no arithmetic."""
+    from oracle import encoders_ref as E
+    from ultrafnd_git_amd.encoders import BertTextEncoder, ClipVisualEncoder
+    from ultrafnd_git_amd.trainer import ForensicTrainer, TrainConfig, synthetic_cache
+    tenc, venc = BertTextEncoder(layers=1, vocab_size=300).to(DEV), ClipVisualEncoder(layers=1).to(DEV)
+    B = 8
+    ids, mask = E.synthetic_tokens(3, B, 32, vocab=300, min_len=4)
+    g = torch.Generator().manual_seed(1)
+    batch = {"input_ids": ids.to(DEV), "attention_mask": mask.to(torch.int32).to(DEV),
+             "frames": torch.randn(B, 2, 3, 224, 224, generator=g).to(DEV), "audio_features": torch.randn(B, 128, generator=g).to(DEV),
+             "temporal_features": torch.randn(B, 256, generator=g).to(DEV), "gnn_feat": torch.randn(B, 128, generator=g).to(DEV),
+             "aux": torch.rand(B, 2, generator=g).to(DEV), "label": torch.randint(0, 2, (B,), generator=g).to(DEV)}
+    outs = []
+    for mode in ("plain", "pipelined"):
+        torch.manual_seed(7)
+        cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir=str(tmp_path), batch_size=B, device=DEV, encode_inline=True)
+        tr = ForensicTrainer(cfg, cache=synthetic_cache(16, seed=1), text_encoder=tenc, visual_encoder=venc)
+        tr.fusion.train(); tr.clf.train()
+        if mode == "plain":
+            for _ in range(3):
+                out = tr.train_step(batch)
+        else:
+            tr.prefetch_features(batch)
+            for i in range(3):
+                out = tr.train_step_pipelined(batch, batch if i < 2 else None)
+        outs.append((out["logits"].clone(), tr.arena.data.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ms, n = tr.measure_gemm_time(batch, steps=1)
+    assert n == 2 * 4 + 2 and ms > 0

@@ -81,28 +81,23 @@ def _declare(lib: C.CDLL) -> None:
 
 
 def _declare_encoders(lib: C.CDLL) -> None:
-    """Tier-B entry points (declared separately so a header/library mismatch is reported by name)."""
+    """Tier-B entry points (include/ultrafnd_hip.h, second half)."""
     P, I, S, F = C.c_void_p, C.c_int, C.c_size_t, C.c_float
-    if not hasattr(lib, "ufnd_gemm_bf16"):
-        return
-    lib.ufnd_gemm_bf16.argtypes = [P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]
-    lib.ufnd_gemm_bf16.restype = I
-    lib.ufnd_layernorm.argtypes = [P, P, P, P, P, I, I, F, P]
-    lib.ufnd_layernorm.restype = I
-    lib.ufnd_attention_bf16.argtypes = [P, P, P, I, I, I, I, P]
-    lib.ufnd_attention_bf16.restype = I
-    lib.ufnd_bert_embed.argtypes = [P, P, P, P, P, P, P, P, I, I, I, F, P]
-    lib.ufnd_bert_embed.restype = I
-    lib.ufnd_masked_meanpool_l2.argtypes = [P, P, P, I, I, I, P]
-    lib.ufnd_masked_meanpool_l2.restype = I
-    lib.ufnd_vit_patchify.argtypes = [P, P, I, I, I, P]
-    lib.ufnd_vit_patchify.restype = I
-    lib.ufnd_vit_assemble.argtypes = [P, P, P, P, P, P, P, I, I, I, F, P]
-    lib.ufnd_vit_assemble.restype = I
-    lib.ufnd_l2norm_frames.argtypes = [P, P, I, I, I, P]
-    lib.ufnd_l2norm_frames.restype = I
-    lib.ufnd_cast_bf16.argtypes = [P, P, S, P]
-    lib.ufnd_cast_bf16.restype = I
+    sigs = {
+        "ufnd_cast_bf16": [P, P, S, P],
+        "ufnd_gemm_bf16": [P] * 6 + [I] * 9 + [P],
+        "ufnd_layernorm": [P, I, P, P, P, P, I, I, F, P],
+        "ufnd_attention_bf16": [P, P, P, I, I, I, P],
+        "ufnd_bert_embed": [P] * 8 + [I, I, I, I, F, P],
+        "ufnd_masked_meanpool_l2": [P, P, P, I, I, I, P],
+        "ufnd_vit_patchify": [P, P, I, I, I, P],
+        "ufnd_vit_assemble": [P] * 6 + [I, I, I, F, P],
+        "ufnd_l2norm_frames": [P, P, I, I, I, P],
+    }
+    for name, argtypes in sigs.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = I
 
 
 def lib() -> C.CDLL:

@@ -1,0 +1,187 @@
+// Multi-head self-attention, forward only: ctx = softmax(Q K^T / sqrt(64) + mask) V.
+// (BertSelfAttention eager path / CLIPAttention; head_dim 64, 12 heads in both encoders.)
+//
+// One workgroup = one (batch, head, 128-query block); wave w owns 32 queries.  Keys/values are
+// walked in blocks of 128 with an online softmax, so L = 50 (ViT), 128 and 512 (BERT) share
+// the code and nothing of size L x L ever exists.
+//
+// MFMA orientation (v_mfma_f32_16x16x32_bf16; C/D: column = lane & 15, row = 4*(lane>>4)+r):
+//   S^T[key][query] = K Q^T      A = K rows from LDS (ds_read_b128, swizzled), B = Q from registers
+//     -> a lane holds ONE query (its column) and 4 keys per tile: the softmax statistics of a
+//        query live in the 4 lanes {q, q+16, q+32, q+48}: two __shfl_xor, no LDS.
+//   O^T[d][query] = V^T P^T      B = P^T: the S^T accumulators, converted to bf16 IN PLACE --
+//        the accumulator layout of step 1 is exactly the B-operand layout of step 2 once the
+//        contraction index is ordered as (keys 4g..4g+3 of tile 2s, keys 4g..4g+3 of tile 2s+1)
+//        A = V^T fragments in that same key order, produced from the row-major V tile in LDS
+//        by ds_read_b64_tr_b16 (hardware transpose): 4 keys x 16 d per 16-lane group.
+// Masking follows HF: masked keys get the constant finfo.min-like score (a fully masked row
+// degenerates to a uniform average, not NaN); keys beyond L contribute exactly zero.
+#include "common.hpp"
+
+namespace {
+
+constexpr int KB = 128;          // keys per block
+constexpr int QB = 128;          // queries per workgroup
+constexpr float NEG_MASK = -3.0e38f;
+
+__device__ __forceinline__ bf16x8 k_frag(const char* tile, int row, int chunk) {
+  return *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+}
+
+__global__ __launch_bounds__(256) void attention_kernel(const __bf16* qkv, const int32_t* mask, __bf16* ctx, int L,
+                                                        int heads, float scale_log2e) {
+  __shared__ __attribute__((aligned(16))) char ks[KB * 128];
+  __shared__ __attribute__((aligned(16))) char vs[KB * 128];
+  __shared__ __attribute__((aligned(16))) float kbias[KB];
+
+  const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int H = heads * 64, ld = 3 * H;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, fr = lane & 15, g = lane >> 4;
+  const size_t tok0 = (size_t)b * L;
+
+  // Q fragments (B operand): lane (query fr, g) holds Q[query][8g + 32kk .. +7]
+  bf16x8 qf[2][2];
+  int qrow[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int q = qb * QB + wave * 32 + qt * 16 + fr;
+    qrow[qt] = q;
+    const int qc = q < L ? q : L - 1;
+    const __bf16* src = qkv + (tok0 + qc) * ld + h * 64 + 8 * g;
+    qf[qt][0] = *reinterpret_cast<const bf16x8*>(src);
+    qf[qt][1] = *reinterpret_cast<const bf16x8*>(src + 32);
+  }
+
+  f32x4 o[4][2];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) o[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+
+  for (int kb0 = 0; kb0 < L; kb0 += KB) {
+    __syncthreads();  // previous block's LDS reads are done
+    // ---- stage K and V tiles (row-major 128-B rows, swizzled 16-B chunks) and the key bias
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + 256 * it, key = idx >> 3, c = idx & 7;
+      const int kr = (kb0 + key) < L ? (kb0 + key) : L - 1;
+      const __bf16* src = qkv + (tok0 + kr) * ld + H + h * 64 + c * 8;
+      const bf16x8 kv = *reinterpret_cast<const bf16x8*>(src);
+      const bf16x8 vv = *reinterpret_cast<const bf16x8*>(src + H);
+      *reinterpret_cast<bf16x8*>(ks + key * 128 + ((c ^ ((key >> 1) & 7)) << 4)) = kv;
+      *reinterpret_cast<bf16x8*>(vs + key * 128 + ((c ^ (((key >> 1) & 3) << 1)) << 4)) = vv;
+    }
+    if (tid < KB) {
+      const int key = kb0 + tid;
+      float bias = -INFINITY;
+      if (key < L) bias = (!mask || mask[tok0 + key] != 0) ? 0.0f : NEG_MASK;
+      kbias[tid] = bias;
+    }
+    __syncthreads();
+
+    // ---- S^T = K Q^T : 8 key tiles x 2 query tiles
+    f32x4 s[8][2];
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) s[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt) {
+        const bf16x8 kf = k_frag(ks, kt * 16 + fr, g + 4 * kk);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][kk], s[kt][qt], 0, 0, 0);
+      }
+
+    // ---- online softmax (scores kept in the log2 domain: exp(x) = exp2(x * log2 e))
+    bf16x8 pf[4][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt) {
+        const f32x4 kbv = *reinterpret_cast<const f32x4*>(kbias + kt * 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = (kbv[r] == 0.0f) ? s[kt][qt][r] * scale_log2e : kbv[r];
+          s[kt][qt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[qt], mx);       // finite: every block holds a key < L
+      const float alpha = exp2f(m_run[qt] - m_new);    // first block: exp2(-inf) = 0
+      float lsum = 0.0f;
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = exp2f(s[kt][qt][r] - m_new);
+          lsum += p;
+          pf[kt >> 1][qt][(kt & 1) * 4 + r] = (__bf16)p;
+        }
+      l_run[qt] = l_run[qt] * alpha + lsum;
+      m_run[qt] = m_new;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[dt][qt] *= alpha;
+    }
+
+    // ---- O^T += V^T P^T : contraction over the block's 128 keys in 4 steps of 32
+#pragma unroll
+    for (int ksd = 0; ksd < 4; ++ksd) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        // hardware-transposed read: 16-lane group g, lane 4q+p supplies &V[key][16dt + 4p]
+        const int qq = fr >> 2, pp = fr & 3;
+        const int key0 = 32 * ksd + 4 * g + qq;
+        const int ch = 2 * dt + (pp >> 1);
+        const int off0 = key0 * 128 + ((ch ^ (((key0 >> 1) & 3) << 1)) << 4) + 8 * (pp & 1);
+        const int key1 = key0 + 16;
+        const int off1 = key1 * 128 + ((ch ^ (((key1 >> 1) & 3) << 1)) << 4) + 8 * (pp & 1);
+        const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vs + off0));
+        const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vs + off1));
+        union { s16x4 s2[2]; bf16x8 v; } u;
+        u.s2[0] = t0;
+        u.s2[1] = t1;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, pf[ksd][qt], o[dt][qt], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- normalise and store: lane holds O^T[d = 16dt + 4g + r][query fr]
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float l = l_run[qt];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    if (qrow[qt] < L) {
+      __bf16* dst = ctx + (tok0 + qrow[qt]) * H + h * 64 + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        bf16x4 ov = {(__bf16)(o[dt][qt][0] * inv), (__bf16)(o[dt][qt][1] * inv), (__bf16)(o[dt][qt][2] * inv),
+                     (__bf16)(o[dt][qt][3] * inv)};
+        *reinterpret_cast<bf16x4*>(dst + dt * 16) = ov;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int ufnd_attention_bf16(const void* qkv, const int32_t* key_mask, void* ctx, int B, int L, int heads,
+                                   void* stream_) {
+  UFND_REQUIRE(qkv && ctx, "attention: null operand");
+  UFND_REQUIRE(B >= 1 && L >= 1 && L <= 4096 && heads >= 1 && heads <= 64, "attention: B=%d L=%d heads=%d", B, L, heads);
+  UFND_REQUIRE(ufnd_aligned(qkv, 16) && ufnd_aligned(ctx, 16), "attention: 16-B alignment required");
+  UFND_REQUIRE(B <= 65535, "attention: B too large for grid.z");
+  const float scale_log2e = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) * log2(e)
+  hipLaunchKernelGGL(attention_kernel, dim3(ufnd_cdiv(L, QB), heads, B), dim3(256), 0, (hipStream_t)stream_,
+                     (const __bf16*)qkv, key_mask, (__bf16*)ctx, L, heads, scale_log2e);
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}

@@ -1,0 +1,257 @@
+// Row-wise pieces of the two encoders: LayerNorm, BERT embeddings, masked mean-pool + L2,
+// ViT patchify / token assembly, frame pooling.  All HBM-bound: one wave per row, 16-B loads,
+// wave-shuffle reductions, fp32 statistics; outputs feed the bf16 GEMMs directly.
+#include "common.hpp"
+
+namespace {
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// normalise NI*4 values per lane (row of H = 256*NI) held in v[]; returns via v[]
+template <int NI>
+__device__ __forceinline__ void ln_row(f32x4 (&v)[NI], int H, float eps, const float* gamma, const float* beta, int lane) {
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float d = v[i][k] - mean;
+      q += d * d;
+    }
+  const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int col = 4 * lane + 256 * i;
+    const f32x4 gm = ld4(gamma + col), bt = ld4(beta + col);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[i][k] = (v[i][k] - mean) * rstd * gm[k] + bt[k];
+  }
+}
+
+template <int NI>
+__device__ __forceinline__ void store_row(const f32x4 (&v)[NI], __bf16* ob, float* of, size_t row, int H, int lane) {
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int col = 4 * lane + 256 * i;
+    if (of) *reinterpret_cast<f32x4*>(of + row * H + col) = v[i];
+    if (ob) {
+      bf16x4 o = {(__bf16)v[i][0], (__bf16)v[i][1], (__bf16)v[i][2], (__bf16)v[i][3]};
+      *reinterpret_cast<bf16x4*>(ob + row * H + col) = o;
+    }
+  }
+}
+
+template <int NI>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, int ldx, const float* gamma, const float* beta,
+                                                        __bf16* ob, float* of, int M, int H, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  f32x4 v[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) v[i] = ld4(x + (size_t)row * ldx + 4 * lane + 256 * i);
+  ln_row<NI>(v, H, eps, gamma, beta, lane);
+  store_row<NI>(v, ob, of, row, H, lane);
+}
+
+template <int NI>
+__global__ __launch_bounds__(256) void bert_embed_kernel(const int64_t* ids, const float* word, const float* pos,
+                                                         const float* type0, const float* gamma, const float* beta,
+                                                         __bf16* ob, float* of, int M, int L, int H, int vocab,
+                                                         float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  long long id = ids[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // never read outside the table
+  const int l = row % L;
+  f32x4 v[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int col = 4 * lane + 256 * i;
+    v[i] = ld4(word + (size_t)id * H + col) + ld4(pos + (size_t)l * H + col) + ld4(type0 + col);
+  }
+  ln_row<NI>(v, H, eps, gamma, beta, lane);
+  store_row<NI>(v, ob, of, row, H, lane);
+}
+
+// masked mean over tokens then L2 normalise; one block per sample, thread owns columns
+__global__ __launch_bounds__(256) void meanpool_l2_kernel(const float* hidden, const int32_t* mask, float* out, int L,
+                                                          int H) {
+  __shared__ float sh[4];
+  const int b = blockIdx.x;
+  float cnt = 0.0f;
+  for (int l = 0; l < L; ++l) cnt += mask[(size_t)b * L + l] != 0 ? 1.0f : 0.0f;
+  const float denom = fmaxf(cnt, 1e-6f);
+  float acc[4] = {0, 0, 0, 0};
+  float sq = 0.0f;
+  int n = 0;
+  for (int c = threadIdx.x; c < H; c += 256, ++n) {
+    float s = 0.0f;
+    for (int l = 0; l < L; ++l)
+      if (mask[(size_t)b * L + l] != 0) s += hidden[((size_t)b * L + l) * H + c];
+    s /= denom;
+    acc[n] = s;
+    sq += s * s;
+  }
+  sq = wave_sum(sq);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sq;
+  __syncthreads();
+  const float nrm = sqrtf((sh[0] + sh[1]) + (sh[2] + sh[3])) + 1e-9f;
+  n = 0;
+  for (int c = threadIdx.x; c < H; c += 256, ++n) out[(size_t)b * H + c] = acc[n] / nrm;
+}
+
+// frames (N,3,S,S) fp32 -> patches (N*G*G, 3*P*P) bf16, element order (c, ky, kx)
+__global__ __launch_bounds__(256) void patchify_kernel(const float* frames, __bf16* patches, int N, int S, int P) {
+  const int G = S / P, K = 3 * P * P;
+  const size_t total4 = (size_t)N * G * G * K / 4;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+    const size_t e = i * 4;
+    const int k = (int)(e % K);
+    const size_t prow = e / K;
+    const int px = (int)(prow % G), py = (int)((prow / G) % G);
+    const size_t n = prow / ((size_t)G * G);
+    const int kx = k % P, ky = (k / P) % P, c = k / (P * P);
+    const f32x4 v = ld4(frames + ((n * 3 + c) * S + (size_t)(py * P + ky)) * S + px * P + kx);
+    bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    *reinterpret_cast<bf16x4*>(patches + e) = o;
+  }
+}
+
+// x[n][0] = cls + pos[0]; x[n][1+p] = patch_emb[n*P+p] + pos[1+p]; then pre-LayerNorm
+template <int NI>
+__global__ __launch_bounds__(256) void vit_assemble_kernel(const float* pe, const float* cls, const float* pos,
+                                                           const float* gamma, const float* beta, float* of, int M,
+                                                           int P, int H, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int n = row / (P + 1), t = row % (P + 1);
+  f32x4 v[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int col = 4 * lane + 256 * i;
+    const f32x4 base = (t == 0) ? ld4(cls + col) : ld4(pe + ((size_t)n * P + (t - 1)) * H + col);
+    v[i] = base + ld4(pos + (size_t)t * H + col);
+  }
+  ln_row<NI>(v, H, eps, gamma, beta, lane);
+  store_row<NI>(v, nullptr, of, row, H, lane);
+}
+
+// per-frame L2 normalise, mean over frames, L2 normalise again (F > 1); one block per sample
+__global__ __launch_bounds__(256) void l2norm_frames_kernel(const float* e, float* out, int F, int D) {
+  __shared__ float sh[4];
+  const int b = blockIdx.x;
+  float acc[4] = {0, 0, 0, 0};
+  for (int f = 0; f < F; ++f) {
+    const float* row = e + ((size_t)b * F + f) * D;
+    float sq = 0.0f;
+    for (int c = threadIdx.x; c < D; c += 256) sq += row[c] * row[c];
+    sq = wave_sum(sq);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    const float nrm = sqrtf((sh[0] + sh[1]) + (sh[2] + sh[3])) + 1e-9f;
+    int n = 0;
+    for (int c = threadIdx.x; c < D; c += 256, ++n) acc[n] += row[c] / nrm;
+  }
+  if (F == 1) {
+    int n = 0;
+    for (int c = threadIdx.x; c < D; c += 256, ++n) out[(size_t)b * D + c] = acc[n];
+    return;
+  }
+  float sq = 0.0f;
+  int n = 0;
+  for (int c = threadIdx.x; c < D; c += 256, ++n) {
+    acc[n] /= (float)F;
+    sq += acc[n] * acc[n];
+  }
+  sq = wave_sum(sq);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sq;
+  __syncthreads();
+  const float nrm = sqrtf((sh[0] + sh[1]) + (sh[2] + sh[3])) + 1e-9f;
+  n = 0;
+  for (int c = threadIdx.x; c < D; c += 256, ++n) out[(size_t)b * D + c] = acc[n] / nrm;
+}
+
+#define NI_LAUNCH(H, KERNEL, GRID, STREAM, ...)                                                       \
+  do {                                                                                                \
+    if ((H) == 256) hipLaunchKernelGGL((KERNEL<1>), GRID, dim3(256), 0, STREAM, __VA_ARGS__);         \
+    else if ((H) == 512) hipLaunchKernelGGL((KERNEL<2>), GRID, dim3(256), 0, STREAM, __VA_ARGS__);    \
+    else if ((H) == 768) hipLaunchKernelGGL((KERNEL<3>), GRID, dim3(256), 0, STREAM, __VA_ARGS__);    \
+    else hipLaunchKernelGGL((KERNEL<4>), GRID, dim3(256), 0, STREAM, __VA_ARGS__);                    \
+  } while (0)
+
+inline bool h_ok(int H) { return H == 256 || H == 512 || H == 768 || H == 1024; }
+
+}  // namespace
+
+extern "C" int ufnd_layernorm(const float* x, int ldx, const float* gamma, const float* beta, void* out_bf16,
+                              float* out_f32, int M, int H, float eps, void* stream_) {
+  UFND_REQUIRE(x && gamma && beta && (out_bf16 || out_f32) && M >= 1, "layernorm: null argument");
+  UFND_REQUIRE(h_ok(H), "layernorm: H=%d (supported 256/512/768/1024)", H);
+  UFND_REQUIRE(ldx % 4 == 0 && ldx >= H && ufnd_aligned(x, 16) && ufnd_aligned(gamma, 16) && ufnd_aligned(beta, 16),
+               "layernorm: alignment");
+  NI_LAUNCH(H, layernorm_kernel, dim3(ufnd_cdiv(M, 4)), (hipStream_t)stream_, x, ldx, gamma, beta, (__bf16*)out_bf16,
+            out_f32, M, H, eps);
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}
+
+extern "C" int ufnd_bert_embed(const int64_t* ids, const float* word, const float* pos, const float* type0,
+                               const float* gamma, const float* beta, void* x_bf16, float* x_f32, int B, int L, int H,
+                               int vocab, float eps, void* stream_) {
+  UFND_REQUIRE(ids && word && pos && type0 && gamma && beta && (x_bf16 || x_f32), "bert_embed: null argument");
+  UFND_REQUIRE(h_ok(H) && B >= 1 && L >= 1 && vocab >= 1, "bert_embed: B=%d L=%d H=%d vocab=%d", B, L, H, vocab);
+  UFND_REQUIRE(ufnd_aligned(word, 16) && ufnd_aligned(pos, 16) && ufnd_aligned(type0, 16), "bert_embed: alignment");
+  const int M = B * L;
+  NI_LAUNCH(H, bert_embed_kernel, dim3(ufnd_cdiv(M, 4)), (hipStream_t)stream_, ids, word, pos, type0, gamma, beta,
+            (__bf16*)x_bf16, x_f32, M, L, H, vocab, eps);
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}
+
+extern "C" int ufnd_masked_meanpool_l2(const float* hidden, const int32_t* mask, float* out, int B, int L, int H,
+                                       void* stream_) {
+  UFND_REQUIRE(hidden && mask && out && B >= 1 && L >= 1, "meanpool: null argument");
+  UFND_REQUIRE(H >= 1 && H <= 1024, "meanpool: H=%d (<= 1024)", H);
+  hipLaunchKernelGGL(meanpool_l2_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream_, hidden, mask, out, L, H);
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}
+
+extern "C" int ufnd_vit_patchify(const float* frames, void* patches, int N, int image, int patch, void* stream_) {
+  UFND_REQUIRE(frames && patches && N >= 1, "patchify: null argument");
+  UFND_REQUIRE(patch % 4 == 0 && image % patch == 0 && ufnd_aligned(frames, 16) && ufnd_aligned(patches, 8),
+               "patchify: image=%d patch=%d", image, patch);
+  const size_t total4 = (size_t)N * (image / patch) * (image / patch) * 3 * patch * patch / 4;
+  const int blocks = (int)(total4 / 256 + 1 > 8192 ? 8192 : total4 / 256 + 1);
+  hipLaunchKernelGGL(patchify_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, frames, (__bf16*)patches, N,
+                     image, patch);
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}
+
+extern "C" int ufnd_vit_assemble(const float* patch_emb, const float* cls, const float* pos, const float* gamma,
+                                 const float* beta, float* x_f32, int N, int P, int H, float eps, void* stream_) {
+  UFND_REQUIRE(patch_emb && cls && pos && gamma && beta && x_f32 && N >= 1 && P >= 1, "vit_assemble: null argument");
+  UFND_REQUIRE(h_ok(H), "vit_assemble: H=%d", H);
+  const int M = N * (P + 1);
+  NI_LAUNCH(H, vit_assemble_kernel, dim3(ufnd_cdiv(M, 4)), (hipStream_t)stream_, patch_emb, cls, pos, gamma, beta, x_f32,
+            M, P, H, eps);
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}
+
+extern "C" int ufnd_l2norm_frames(const float* e, float* out, int B, int F, int D, void* stream_) {
+  UFND_REQUIRE(e && out && B >= 1 && F >= 1 && D >= 1 && D <= 1024, "l2norm_frames: B=%d F=%d D=%d", B, F, D);
+  hipLaunchKernelGGL(l2norm_frames_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream_, e, out, F, D);
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}

@@ -1,0 +1,316 @@
+"""Frozen, forward-only encoders that produce the `text` (B,768) and `visual` (B,512) inputs of
+the fusion step, MI355X-native.
+
+  BertTextEncoder   replaces BERTContextEncoder.encode's model call + pooling
+                    (src/core_blocks/text_blocks.py:71-101): BertModel(...).last_hidden_state
+                    -> masked mean-pool -> L2-norm, batched over (B, L) instead of one
+                    string at a time.  Tokenisation stays outside (ids/mask in), there is
+                    no tokenizer vocabulary offline.
+  ClipVisualEncoder the ViT-B/32 @224 geometry the reference points at
+                    (configs/model_configs/semantic.yaml:2): pooled -> bias-free projection ->
+                    L2-norm; multi-frame = mean over frames, L2-norm again
+                    (text_blocks.py:126-128 idiom).
+
+Weights keep the third-party `state_dict` names so real checkpoints load unchanged; fp32
+masters are converted once to bf16 MFMA operands (Q/K/V stacked into one (3H,H) matrix).
+Every Linear is `ufnd_gemm_bf16` with fused bias / GELU / residual epilogues; the residual
+stream and all LayerNorm / softmax statistics stay fp32.  No CPU path.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+
+ACT_NONE, ACT_GELU, ACT_QUICK_GELU = 0, 1, 2
+
+
+def _bf16(t: torch.Tensor) -> torch.Tensor:
+    """fp32 device tensor -> bf16 copy through the library's own cast kernel."""
+    t = t.contiguous()
+    out = torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
+    L.check(L.lib().ufnd_cast_bf16(t.data_ptr(), out.data_ptr(), t.numel(), L.stream_ptr(t.device)), "ufnd_cast_bf16")
+    return out
+
+
+class _EncoderBase(nn.Module):
+    """Weight store with third-party key names + lazily packed bf16 operands + per-shape buffers."""
+
+    def __init__(self):
+        super().__init__()
+        self._w: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+        self._packed: Optional[dict] = None
+        self._bufs: Dict[Tuple, dict] = {}
+
+    # ---- state_dict with the third-party names
+    def state_dict(self, *args, **kwargs):
+        return OrderedDict((k, v.detach().clone()) for k, v in self._w.items())
+
+    def load_state_dict(self, sd, strict: bool = True):
+        missing = [k for k in self._w if k not in sd]
+        unexpected = [k for k in sd if k not in self._w]
+        if strict and missing:
+            raise RuntimeError(f"missing keys: {missing[:5]}{'...' if len(missing) > 5 else ''}")
+        for k in self._w:
+            if k in sd:
+                if tuple(sd[k].shape) != tuple(self._w[k].shape):
+                    raise RuntimeError(f"shape mismatch for {k}: {tuple(sd[k].shape)} vs {tuple(self._w[k].shape)}")
+                self._w[k].copy_(sd[k].to(self._w[k].device, torch.float32))
+        self._packed = None
+        return missing, unexpected
+
+    def _apply(self, fn, recurse=True):
+        super()._apply(fn, recurse)
+        for k in self._w:
+            self._w[k] = fn(self._w[k]).float()
+        self._packed = None
+        self._bufs.clear()
+        return self
+
+    @property
+    def device(self) -> torch.device:
+        return next(iter(self._w.values())).device
+
+    def _require_hip(self):
+        if self.device.type != "cuda":
+            raise L.UltrafndHipError(f"{type(self).__name__} runs on a HIP device only: call .to('cuda') (no CPU fallback)")
+
+    # ---- thin wrappers over the C ABI
+    def _gemm(self, A, W, bias, out_bf16=None, out_f32=None, residual=None, act=ACT_NONE, M=None):
+        M = A.shape[0] if M is None else M
+        N, K = W.shape
+        L.check(L.lib().ufnd_gemm_bf16(A.data_ptr(), W.data_ptr(), L.ptr(bias), L.ptr(residual), L.ptr(out_bf16),
+                                       L.ptr(out_f32), M, N, K, A.stride(0), W.stride(0),
+                                       residual.stride(0) if residual is not None else 0,
+                                       out_bf16.stride(0) if out_bf16 is not None else 0,
+                                       out_f32.stride(0) if out_f32 is not None else 0, act,
+                                       L.stream_ptr(A.device)), "ufnd_gemm_bf16")
+
+    def _ln(self, x, ldx, gamma, beta, out_bf16, out_f32, M, H, eps):
+        L.check(L.lib().ufnd_layernorm(x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), L.ptr(out_bf16),
+                                       L.ptr(out_f32), M, H, eps, L.stream_ptr(x.device)), "ufnd_layernorm")
+
+    def _attn(self, qkv, mask_i32, ctx, B, Lq, heads):
+        L.check(L.lib().ufnd_attention_bf16(qkv.data_ptr(), L.ptr(mask_i32), ctx.data_ptr(), B, Lq, heads,
+                                            L.stream_ptr(qkv.device)), "ufnd_attention_bf16")
+
+
+# =============================================================================================
+class BertTextEncoder(_EncoderBase):
+    def __init__(self, layers: int = 12, hidden: int = 768, heads: int = 12, intermediate: int = 3072,
+                 vocab_size: int = 30522, max_position: int = 512, type_vocab: int = 2, eps: float = 1e-12):
+        super().__init__()
+        if hidden != heads * 64:
+            raise ValueError("head_dim must be 64 (hidden == heads * 64)")
+        self.layers, self.hidden, self.heads, self.inter, self.vocab, self.eps = layers, hidden, heads, intermediate, vocab_size, eps
+        self.max_position = max_position
+        w = self._w
+        g = torch.Generator().manual_seed(0)
+
+        def init(shape, std=0.02):
+            return torch.randn(shape, generator=g) * std
+        w["embeddings.word_embeddings.weight"] = init((vocab_size, hidden))
+        w["embeddings.position_embeddings.weight"] = init((max_position, hidden))
+        w["embeddings.token_type_embeddings.weight"] = init((type_vocab, hidden))
+        w["embeddings.LayerNorm.weight"] = torch.ones(hidden)
+        w["embeddings.LayerNorm.bias"] = torch.zeros(hidden)
+        for i in range(layers):
+            P = f"encoder.layer.{i}."
+            for n in ("query", "key", "value"):
+                w[P + f"attention.self.{n}.weight"] = init((hidden, hidden))
+                w[P + f"attention.self.{n}.bias"] = torch.zeros(hidden)
+            w[P + "attention.output.dense.weight"] = init((hidden, hidden))
+            w[P + "attention.output.dense.bias"] = torch.zeros(hidden)
+            w[P + "attention.output.LayerNorm.weight"] = torch.ones(hidden)
+            w[P + "attention.output.LayerNorm.bias"] = torch.zeros(hidden)
+            w[P + "intermediate.dense.weight"] = init((intermediate, hidden))
+            w[P + "intermediate.dense.bias"] = torch.zeros(intermediate)
+            w[P + "output.dense.weight"] = init((hidden, intermediate))
+            w[P + "output.dense.bias"] = torch.zeros(hidden)
+            w[P + "output.LayerNorm.weight"] = torch.ones(hidden)
+            w[P + "output.LayerNorm.bias"] = torch.zeros(hidden)
+
+    def _pack(self):
+        if self._packed is None:
+            w, layers = self._w, []
+            for i in range(self.layers):
+                P = f"encoder.layer.{i}."
+                layers.append({
+                    "wqkv": _bf16(torch.cat([w[P + f"attention.self.{n}.weight"] for n in ("query", "key", "value")], 0)),
+                    "bqkv": torch.cat([w[P + f"attention.self.{n}.bias"] for n in ("query", "key", "value")], 0).contiguous(),
+                    "wo": _bf16(w[P + "attention.output.dense.weight"]), "bo": w[P + "attention.output.dense.bias"],
+                    "g1": w[P + "attention.output.LayerNorm.weight"], "b1": w[P + "attention.output.LayerNorm.bias"],
+                    "w1": _bf16(w[P + "intermediate.dense.weight"]), "bi": w[P + "intermediate.dense.bias"],
+                    "w2": _bf16(w[P + "output.dense.weight"]), "b2": w[P + "output.dense.bias"],
+                    "g2": w[P + "output.LayerNorm.weight"], "b2n": w[P + "output.LayerNorm.bias"]})
+            self._packed = {"layers": layers}
+        return self._packed
+
+    def _workbufs(self, B: int, Lq: int) -> dict:
+        key = (B, Lq)
+        if key not in self._bufs:
+            dev, M, H = self.device, B * Lq, self.hidden
+            bf, f32 = dict(dtype=torch.bfloat16, device=dev), dict(dtype=torch.float32, device=dev)
+            self._bufs[key] = {"xb": torch.empty(M, H, **bf), "xf": torch.empty(M, H, **f32), "y": torch.empty(M, H, **f32),
+                               "x1b": torch.empty(M, H, **bf), "x1f": torch.empty(M, H, **f32),
+                               "qkv": torch.empty(M, 3 * H, **bf), "ctx": torch.empty(M, H, **bf),
+                               "h": torch.empty(M, self.inter, **bf), "feat": torch.empty(B, H, **f32)}
+        return self._bufs[key]
+
+    @torch.no_grad()
+    def last_hidden_state(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
+        """BertModel(input_ids, attention_mask).last_hidden_state -> (B, L, H) fp32 (a view of an
+        internal buffer, valid until the next call with the same shape)."""
+        self._require_hip()
+        dev = self.device
+        B, Lq = input_ids.shape
+        if Lq > self.max_position:
+            raise RuntimeError(f"sequence length {Lq} exceeds max_position_embeddings {self.max_position}")
+        ids = input_ids.to(dev, torch.int64).contiguous()
+        mask = attention_mask.to(dev, torch.int32).contiguous()
+        self._mask_i32 = mask
+        p, b, w = self._pack(), self._workbufs(B, Lq), self._w
+        M, H = B * Lq, self.hidden
+        L.check(L.lib().ufnd_bert_embed(ids.data_ptr(), w["embeddings.word_embeddings.weight"].data_ptr(),
+                                        w["embeddings.position_embeddings.weight"].data_ptr(),
+                                        w["embeddings.token_type_embeddings.weight"].data_ptr(),
+                                        w["embeddings.LayerNorm.weight"].data_ptr(), w["embeddings.LayerNorm.bias"].data_ptr(),
+                                        b["xb"].data_ptr(), b["xf"].data_ptr(), B, Lq, H, self.vocab, self.eps,
+                                        L.stream_ptr(dev)), "ufnd_bert_embed")
+        for ly in p["layers"]:
+            self._gemm(b["xb"], ly["wqkv"], ly["bqkv"], out_bf16=b["qkv"])
+            self._attn(b["qkv"], mask, b["ctx"], B, Lq, self.heads)
+            self._gemm(b["ctx"], ly["wo"], ly["bo"], out_f32=b["y"], residual=b["xf"])
+            self._ln(b["y"], H, ly["g1"], ly["b1"], b["x1b"], b["x1f"], M, H, self.eps)
+            self._gemm(b["x1b"], ly["w1"], ly["bi"], out_bf16=b["h"], act=ACT_GELU)
+            self._gemm(b["h"], ly["w2"], ly["b2"], out_f32=b["y"], residual=b["x1f"])
+            self._ln(b["y"], H, ly["g2"], ly["b2n"], b["xb"], b["xf"], M, H, self.eps)
+        return b["xf"].view(B, Lq, H)
+
+    @torch.no_grad()
+    def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
+        """Batched BERTContextEncoder.encode: (B,L) ids/mask -> (B,768) L2-normalised features."""
+        hid = self.last_hidden_state(input_ids, attention_mask)
+        B, Lq, H = hid.shape
+        feat = self._workbufs(B, Lq)["feat"]
+        L.check(L.lib().ufnd_masked_meanpool_l2(hid.data_ptr(), self._mask_i32.data_ptr(), feat.data_ptr(), B, Lq, H,
+                                                L.stream_ptr(self.device)), "ufnd_masked_meanpool_l2")
+        return feat
+
+    encode_batch = forward
+
+
+# =============================================================================================
+class ClipVisualEncoder(_EncoderBase):
+    def __init__(self, layers: int = 12, hidden: int = 768, heads: int = 12, intermediate: int = 3072, patch: int = 32,
+                 image: int = 224, projection_dim: int = 512, eps: float = 1e-5):
+        super().__init__()
+        if hidden != heads * 64:
+            raise ValueError("head_dim must be 64 (hidden == heads * 64)")
+        self.layers, self.hidden, self.heads, self.inter = layers, hidden, heads, intermediate
+        self.patch, self.image, self.proj, self.eps = patch, image, projection_dim, eps
+        self.n_patches = (image // patch) ** 2
+        w, V = self._w, "vision_model."
+        g = torch.Generator().manual_seed(0)
+
+        def init(shape, std=0.02):
+            return torch.randn(shape, generator=g) * std
+        w[V + "embeddings.class_embedding"] = init((hidden,))
+        w[V + "embeddings.patch_embedding.weight"] = init((hidden, 3, patch, patch))
+        w[V + "embeddings.position_embedding.weight"] = init((self.n_patches + 1, hidden))
+        w[V + "pre_layrnorm.weight"], w[V + "pre_layrnorm.bias"] = torch.ones(hidden), torch.zeros(hidden)
+        for i in range(layers):
+            P = V + f"encoder.layers.{i}."
+            for n in ("k_proj", "v_proj", "q_proj", "out_proj"):
+                w[P + f"self_attn.{n}.weight"] = init((hidden, hidden))
+                w[P + f"self_attn.{n}.bias"] = torch.zeros(hidden)
+            w[P + "layer_norm1.weight"], w[P + "layer_norm1.bias"] = torch.ones(hidden), torch.zeros(hidden)
+            w[P + "mlp.fc1.weight"], w[P + "mlp.fc1.bias"] = init((intermediate, hidden)), torch.zeros(intermediate)
+            w[P + "mlp.fc2.weight"], w[P + "mlp.fc2.bias"] = init((hidden, intermediate)), torch.zeros(hidden)
+            w[P + "layer_norm2.weight"], w[P + "layer_norm2.bias"] = torch.ones(hidden), torch.zeros(hidden)
+        w[V + "post_layernorm.weight"], w[V + "post_layernorm.bias"] = torch.ones(hidden), torch.zeros(hidden)
+        w["visual_projection.weight"] = init((projection_dim, hidden))
+
+    def _pack(self):
+        if self._packed is None:
+            w, V, layers = self._w, "vision_model.", []
+            for i in range(self.layers):
+                P = V + f"encoder.layers.{i}."
+                layers.append({
+                    "wqkv": _bf16(torch.cat([w[P + f"self_attn.{n}.weight"] for n in ("q_proj", "k_proj", "v_proj")], 0)),
+                    "bqkv": torch.cat([w[P + f"self_attn.{n}.bias"] for n in ("q_proj", "k_proj", "v_proj")], 0).contiguous(),
+                    "wo": _bf16(w[P + "self_attn.out_proj.weight"]), "bo": w[P + "self_attn.out_proj.bias"],
+                    "g1": w[P + "layer_norm1.weight"], "b1": w[P + "layer_norm1.bias"],
+                    "w1": _bf16(w[P + "mlp.fc1.weight"]), "bi": w[P + "mlp.fc1.bias"],
+                    "w2": _bf16(w[P + "mlp.fc2.weight"]), "b2": w[P + "mlp.fc2.bias"],
+                    "g2": w[P + "layer_norm2.weight"], "b2n": w[P + "layer_norm2.bias"]})
+            self._packed = {"layers": layers,
+                            "wpatch": _bf16(w[V + "embeddings.patch_embedding.weight"].reshape(self.hidden, -1)),
+                            "wproj": _bf16(w["visual_projection.weight"])}
+        return self._packed
+
+    def _workbufs(self, B: int, Fr: int) -> dict:
+        key = (B, Fr)
+        if key not in self._bufs:
+            dev, H, N = self.device, self.hidden, B * Fr
+            T = self.n_patches + 1
+            M = N * T
+            bf, f32 = dict(dtype=torch.bfloat16, device=dev), dict(dtype=torch.float32, device=dev)
+            self._bufs[key] = {"patches": torch.empty(N * self.n_patches, 3 * self.patch ** 2, **bf),
+                               "pe": torch.empty(N * self.n_patches, H, **f32), "xf": torch.empty(M, H, **f32),
+                               "hb": torch.empty(M, H, **bf), "qkv": torch.empty(M, 3 * H, **bf),
+                               "ctx": torch.empty(M, H, **bf), "m": torch.empty(M, self.inter, **bf),
+                               "pooled": torch.empty(N, H, **bf), "e": torch.empty(N, self.proj, **f32),
+                               "feat": torch.empty(B, self.proj, **f32)}
+        return self._bufs[key]
+
+    @torch.no_grad()
+    def image_embeds(self, frames: torch.Tensor) -> torch.Tensor:
+        """frames (N,3,S,S) fp32 -> un-normalised projected embeddings (N, 512)
+        (CLIPVisionModelWithProjection.image_embeds)."""
+        return self._run(frames[:, None])[0]
+
+    def _run(self, frames5: torch.Tensor):
+        self._require_hip()
+        dev = self.device
+        B, Fr = frames5.shape[:2]
+        if tuple(frames5.shape[2:]) != (3, self.image, self.image):
+            raise RuntimeError(f"frames: expected (B,F,3,{self.image},{self.image}), got {tuple(frames5.shape)}")
+        fr = L.f32c(frames5.to(dev)).view(B * Fr, 3, self.image, self.image)
+        p, b, w, V = self._pack(), self._workbufs(B, Fr), self._w, "vision_model."
+        N, H, T = B * Fr, self.hidden, self.n_patches + 1
+        M = N * T
+        s = L.stream_ptr(dev)
+        L.check(L.lib().ufnd_vit_patchify(fr.data_ptr(), b["patches"].data_ptr(), N, self.image, self.patch, s), "ufnd_vit_patchify")
+        self._gemm(b["patches"], p["wpatch"], None, out_f32=b["pe"])
+        L.check(L.lib().ufnd_vit_assemble(b["pe"].data_ptr(), w[V + "embeddings.class_embedding"].data_ptr(),
+                                          w[V + "embeddings.position_embedding.weight"].data_ptr(),
+                                          w[V + "pre_layrnorm.weight"].data_ptr(), w[V + "pre_layrnorm.bias"].data_ptr(),
+                                          b["xf"].data_ptr(), N, self.n_patches, H, self.eps, s), "ufnd_vit_assemble")
+        for ly in p["layers"]:
+            self._ln(b["xf"], H, ly["g1"], ly["b1"], b["hb"], None, M, H, self.eps)
+            self._gemm(b["hb"], ly["wqkv"], ly["bqkv"], out_bf16=b["qkv"])
+            self._attn(b["qkv"], None, b["ctx"], N, T, self.heads)
+            self._gemm(b["ctx"], ly["wo"], ly["bo"], out_f32=b["xf"], residual=b["xf"])
+            self._ln(b["xf"], H, ly["g2"], ly["b2n"], b["hb"], None, M, H, self.eps)
+            self._gemm(b["hb"], ly["w1"], ly["bi"], out_bf16=b["m"], act=ACT_QUICK_GELU)
+            self._gemm(b["m"], ly["w2"], ly["b2"], out_f32=b["xf"], residual=b["xf"])
+        # post-LN on the CLS rows (row stride T*H), bias-free projection
+        self._ln(b["xf"], T * H, w[V + "post_layernorm.weight"], w[V + "post_layernorm.bias"], b["pooled"], None, N, H, self.eps)
+        self._gemm(b["pooled"], p["wproj"], None, out_f32=b["e"])
+        return b["e"], b
+
+    @torch.no_grad()
+    def forward(self, frames: torch.Tensor) -> torch.Tensor:
+        """frames (B,F,3,224,224) or (B,3,224,224) -> (B,512) features."""
+        if frames.dim() == 4:
+            frames = frames[:, None]
+        B, Fr = frames.shape[:2]
+        e, b = self._run(frames)
+        L.check(L.lib().ufnd_l2norm_frames(e.data_ptr(), b["feat"].data_ptr(), B, Fr, self.proj, L.stream_ptr(self.device)),
+                "ufnd_l2norm_frames")
+        return b["feat"]
