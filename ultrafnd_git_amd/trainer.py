@@ -358,7 +358,16 @@ class ForensicTrainer:
         finally:
             for enc, orig in originals:
                 enc._gemm = orig
-        total = sum(e0.elapsed_time(e1) for e0, e1 in events)
+        # an event pair around nothing still reads a few us: calibrate it and take it off each launch
+        pairs = []
+        for _ in range(64):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            e1.record()
+            pairs.append((e0, e1))
+        torch.cuda.synchronize(self.device)
+        empty = sorted(e0.elapsed_time(e1) for e0, e1 in pairs)[len(pairs) // 2]
+        total = sum(max(0.0, e0.elapsed_time(e1) - empty) for e0, e1 in events)
         return total / steps, len(events) // steps
 
     def _forward_batch(self, batch, split: str) -> Dict[str, torch.Tensor]:
