@@ -198,6 +198,13 @@ int ufnd_gemm_bf16(const void* A, const void* W, const float* bias, const float*
                    float* out_f32, int M, int N, int K, int lda, int ldw, int ldr, int ldo, int ldf, int act,
                    void* stream);
 
+/* Same, with an explicit tile configuration (tuning / benchmarking): tile_cfg < 0 = automatic;
+ * 0: 128x128 3-stage, 1: 128x64 3-stage, 2: 256x128 3-stage (8 waves), 3: 128x128 2-stage,
+ * 4: 128x64 4-stage, 5: 256x64 3-stage (8 waves).  N must be a multiple of the tile width. */
+int ufnd_gemm_bf16_ex(const void* A, const void* W, const float* bias, const float* residual, void* out_bf16,
+                      float* out_f32, int M, int N, int K, int lda, int ldw, int ldr, int ldo, int ldf, int act,
+                      int tile_cfg, void* stream);
+
 /* y = LayerNorm(x) * gamma + beta over the last dim (H % 256 == 0, H <= 1024).
  *   x fp32 rows with stride ldx; outputs (M,H) contiguous: bf16 (next GEMM's operand) and/or
  *   fp32 (the residual stream). */

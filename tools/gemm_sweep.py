@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Sweep ufnd_gemm_bf16_ex tile configurations over the encoder GEMM shapes (GPU box).
+Interleaved rounds in ONE process (variants x rounds), median of per-launch HIP-event times minus
+the empty event-pair time, random operands.  Every variant is first checked against an fp32 torch
+matmul of the same bf16 data.   usage: gemm_sweep.py [rounds] [--ablate]"""
+import json
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch
+
+from ultrafnd_git_amd import _lib as L
+
+DEV = "cuda"
+SHAPES = [("bert_qkv", 4096, 2304, 768), ("bert_out", 4096, 768, 768), ("bert_ffn1", 4096, 3072, 768),
+          ("bert_ffn2", 4096, 768, 3072), ("vit_qkv", 1600, 2304, 768), ("vit_out", 1600, 768, 768),
+          ("vit_ffn1", 1600, 3072, 768), ("vit_ffn2", 1600, 768, 3072), ("vit_patch", 1568, 768, 3072)]
+TILES = {0: (128, 128, "2x2x3"), 1: (128, 64, "2x2x3"), 2: (256, 128, "4x2x3"), 3: (128, 128, "2x2x2"), 4: (128, 64, "2x2x4"),
+         5: (256, 64, "4x2x3"), 6: (128, 288, "2x2x3"), 7: (128, 96, "2x2x3"), 8: (256, 192, "4x2x2"), 9: (128, 384, "2x2x2"),
+         10: (128, 192, "2x2x3"), 11: (128, 96, "2x2x4"), 12: (64, 96, "1x2x4"), 13: (64, 192, "1x2x3"), 14: (128, 256, "2x2x2"),
+         15: (256, 256, "4x2x2"), 16: (128, 128, "4x2x3"), 17: (128, 192, "4x2x3"), 18: (256, 64, "4x2x4"), 19: (64, 64, "1x2x4"),
+         20: (128, 64, "4x2x4"), 21: (256, 192, "2x4x2")}
+
+
+def run(cfg, A, W, bias, ob, M, N, K):
+    L.check(L.lib().ufnd_gemm_bf16_ex(A.data_ptr(), W.data_ptr(), bias.data_ptr(), None, ob.data_ptr(), None, M, N, K, K, K, 0,
+                                      N, 0, 0, cfg, L.stream_ptr(A.device)), "gemm_ex")
+
+
+def empty_pair_ms():
+    ev = []
+    for _ in range(64):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); e1.record()
+        ev.append((e0, e1))
+    torch.cuda.synchronize()
+    t = sorted(a.elapsed_time(b) for a, b in ev)
+    return t[len(t) // 2]
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 5
+    ablate = "--ablate" in sys.argv
+    out = {}
+    for name, M, N, K in SHAPES:
+        g = torch.Generator().manual_seed(M + N)
+        A = torch.randn(M, K, generator=g).to(DEV).bfloat16()
+        W = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV).bfloat16()
+        bias = torch.randn(N, generator=g).to(DEV)
+        ob = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        ref = A.float() @ W.float().t() + bias
+        cfgs = [c for c, (bm, bn, _) in TILES.items() if N % bn == 0]
+        for c in cfgs:
+            ob.zero_()
+            run(c, A, W, bias, ob, M, N, K)
+            torch.cuda.synchronize()
+            err = (ob.float() - ref).abs().max().item()
+            assert err <= 0.05 * max(1.0, ref.abs().max().item()), (name, c, err)
+        variants = list(cfgs)
+        if ablate:
+            variants += [100 + c for c in cfgs] + [200 + c for c in cfgs]
+        times = {c: [] for c in variants}
+        empty = empty_pair_ms()
+        for _ in range(rounds):
+            for c in variants:
+                evs = []
+                for _ in range(8):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(); run(c, A, W, bias, ob, M, N, K); e1.record()
+                    evs.append((e0, e1))
+                torch.cuda.synchronize()
+                times[c] += [a.elapsed_time(b) - empty for a, b in evs]
+        row = {}
+        for c in variants:
+            t = sorted(times[c])
+            med = t[len(t) // 2] * 1e-3
+            bm, bn, lay = TILES[c % 100]
+            tag = f"{c % 100}:{bm}x{bn}/{lay}" + {0: "", 1: "-noMFMA", 2: "-noDMA"}[c // 100]
+            tiles = -(-M // bm) * (N // bn)
+            row[tag] = {"us": round(med * 1e6, 2), "tflops": round(2.0 * M * N * K / med / 1e12, 1), "tiles": tiles}
+        out[name] = row
+        print(f"== {name} M={M} N={N} K={K} (empty event pair {empty * 1e3:.1f} us)")
+        for k, v in sorted(row.items(), key=lambda kv: kv[1]["us"]):
+            print(f"   {k:28s} {v['us']:7.1f} us {v['tflops']:7.1f} TF  tiles {v['tiles']}")
+    Path("gpurun_out").mkdir(exist_ok=True)
+    Path("gpurun_out/gemm_sweep.json").write_text(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -79,31 +79,39 @@ __global__ __launch_bounds__(256) void bert_embed_kernel(const int64_t* ids, con
   store_row<NI>(v, ob, of, row, H, lane);
 }
 
-// masked mean over tokens then L2 normalise; one block per sample, thread owns columns
-__global__ __launch_bounds__(256) void meanpool_l2_kernel(const float* hidden, const int32_t* mask, float* out, int L,
-                                                          int H) {
-  __shared__ float sh[4];
-  const int b = blockIdx.x;
+// masked mean over tokens (phase 1: grid (H/256, B), 256 threads = 4 token-groups x 64 lanes x 4 columns,
+// LDS-reduced), then L2 normalise (phase 2, one block per sample).  text_blocks.py:82-86,100.
+__global__ __launch_bounds__(256) void meanpool_kernel(const float* hidden, const int32_t* mask, float* out, int L, int H) {
+  __shared__ f32x4 part[4][64];
+  __shared__ float cnts[4];
+  const int b = blockIdx.y, col = blockIdx.x * 256 + 4 * (threadIdx.x & 63), grp = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   float cnt = 0.0f;
-  for (int l = 0; l < L; ++l) cnt += mask[(size_t)b * L + l] != 0 ? 1.0f : 0.0f;
-  const float denom = fmaxf(cnt, 1e-6f);
-  float acc[4] = {0, 0, 0, 0};
-  float sq = 0.0f;
-  int n = 0;
-  for (int c = threadIdx.x; c < H; c += 256, ++n) {
-    float s = 0.0f;
-    for (int l = 0; l < L; ++l)
-      if (mask[(size_t)b * L + l] != 0) s += hidden[((size_t)b * L + l) * H + c];
-    s /= denom;
-    acc[n] = s;
-    sq += s * s;
+  for (int l = grp; l < L; l += 4) {
+    if (mask[(size_t)b * L + l] != 0) {
+      acc += ld4(hidden + ((size_t)b * L + l) * H + col);
+      cnt += 1.0f;
+    }
   }
+  part[grp][lane] = acc;
+  if (lane == 0) cnts[grp] = cnt;
+  __syncthreads();
+  if (grp == 0) {
+    const f32x4 s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    const float denom = fmaxf((cnts[0] + cnts[1]) + (cnts[2] + cnts[3]), 1e-6f);
+    *reinterpret_cast<f32x4*>(out + (size_t)b * H + col) = s / denom;
+  }
+}
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(float* x, int H) {
+  __shared__ float sh[4];
+  float* row = x + (size_t)blockIdx.x * H;
+  float sq = 0.0f;
+  for (int c = threadIdx.x; c < H; c += 256) sq += row[c] * row[c];
   sq = wave_sum(sq);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sq;
   __syncthreads();
   const float nrm = sqrtf((sh[0] + sh[1]) + (sh[2] + sh[3])) + 1e-9f;
-  n = 0;
-  for (int c = threadIdx.x; c < H; c += 256, ++n) out[(size_t)b * H + c] = acc[n] / nrm;
+  for (int c = threadIdx.x; c < H; c += 256) row[c] = row[c] / nrm;
 }
 
 // frames (N,3,S,S) fp32 -> patches (N*G*G, 3*P*P) bf16, element order (c, ky, kx)
@@ -220,8 +228,10 @@ extern "C" int ufnd_bert_embed(const int64_t* ids, const float* word, const floa
 extern "C" int ufnd_masked_meanpool_l2(const float* hidden, const int32_t* mask, float* out, int B, int L, int H,
                                        void* stream_) {
   UFND_REQUIRE(hidden && mask && out && B >= 1 && L >= 1, "meanpool: null argument");
-  UFND_REQUIRE(H >= 1 && H <= 1024, "meanpool: H=%d (<= 1024)", H);
-  hipLaunchKernelGGL(meanpool_l2_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream_, hidden, mask, out, L, H);
+  UFND_REQUIRE(H >= 256 && H % 256 == 0 && ufnd_aligned(hidden, 16) && ufnd_aligned(out, 16), "meanpool: H=%d (multiple of 256)", H);
+  hipLaunchKernelGGL(meanpool_kernel, dim3(H / 256, B), dim3(256), 0, (hipStream_t)stream_, hidden, mask, out, L, H);
+  UFND_CHECK_LAUNCH();
+  hipLaunchKernelGGL(l2norm_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream_, out, H);
   UFND_CHECK_LAUNCH();
   return UFND_OK;
 }

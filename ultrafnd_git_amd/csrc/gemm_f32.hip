@@ -77,8 +77,32 @@ __global__ __launch_bounds__(256) void nt_kernel(const NtArgs args) {
     xrow[t] = P.X + (size_t)(xok[t] ? m : 0) * P.ldx;
   }
 
+  // Batches of U 8-wide chunks: every load of a batch is issued before its first MFMA, so a wave
+  // keeps U x (1 + MT) 16-B loads in flight (the loop is latency-bound, not bandwidth-bound).
+  constexpr int U = 4;
   int k = k0;
-#pragma unroll 4
+  for (; k + 8 * U <= k1; k += 8 * U) {
+    float a[U][4], b[U][MT][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int kk = k + 8 * u + 4 * h;
+      load_vec<WVEC>(wrow + kk, a[u]);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        if (xok[t]) {
+          load_vec<4>(xrow[t] + kk, b[u][t]);
+        } else {
+          b[u][t][0] = b[u][t][1] = b[u][t][2] = b[u][t][3] = 0.0f;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e], b[u][t][e], acc[t], 0, 0, 0);
+  }
   for (; k + 8 <= k1; k += 8) {
     const int kk = k + 4 * h;
     float a[4];
@@ -194,36 +218,42 @@ __global__ __launch_bounds__(256) void nn_kernel(const NnArgs args) {
   const bool kok = kcol < P.K;  // K % VEC == 0 (host-checked)
   const float* wcol = P.W + (kok ? kcol : 0);
 
-#pragma unroll 2
-  for (int n = n0; n < n1; n += 8) {
-    const int nn = n + 4 * h;
-    float a[4];
-    if (mok) {
-      load_vec<4>(dyrow + nn, a);
-    } else {
-      a[0] = a[1] = a[2] = a[3] = 0.0f;
-    }
-    float b[4][VEC];
+  // batches of U chunks (8 weight rows each): all 5U loads of a batch in flight before its MFMAs
+  constexpr int U = (VEC == 4) ? 4 : 6;
+  for (int n = n0; n < n1; n += 8 * U) {
+    float a[U][4], b[U][4][VEC];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float* src = wcol + (size_t)(nn + e) * P.ldw;
-      if (kok) {
-        if constexpr (VEC == 4) {
-          const f32x4 t = *reinterpret_cast<const f32x4*>(src);
-          b[e][0] = t[0]; b[e][1] = t[1]; b[e][2] = t[2]; b[e][3] = t[3];
-        } else {
-          const f32x2 t = *reinterpret_cast<const f32x2*>(src);
-          b[e][0] = t[0]; b[e][1] = t[1];
-        }
+    for (int u = 0; u < U; ++u) {
+      const int nn = n + 8 * u + 4 * h;
+      const bool nok = (n + 8 * u) < n1;
+      if (mok && nok) {
+        load_vec<4>(dyrow + nn, a[u]);
       } else {
+        a[u][0] = a[u][1] = a[u][2] = a[u][3] = 0.0f;
+      }
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) b[e][v] = 0.0f;
+      for (int e = 0; e < 4; ++e) {
+        const float* src = wcol + (size_t)(nn + e) * P.ldw;
+        if (kok && nok) {
+          if constexpr (VEC == 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(src);
+            b[u][e][0] = t[0]; b[u][e][1] = t[1]; b[u][e][2] = t[2]; b[u][e][3] = t[3];
+          } else {
+            const f32x2 t = *reinterpret_cast<const f32x2*>(src);
+            b[u][e][0] = t[0]; b[u][e][1] = t[1];
+          }
+        } else {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) b[u][e][v] = 0.0f;
+        }
       }
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) acc[v] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e][v], acc[v], 0, 0, 0);
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e], b[u][e][v], acc[v], 0, 0, 0);
   }
 
 #pragma unroll
@@ -304,34 +334,39 @@ __global__ __launch_bounds__(256) void tn_kernel(const TnArgs args) {
   const float* dycol = P.dY + n0 + j;
   const float* xcol = P.X + (kok ? kcol : 0);
 
-#pragma unroll 2
-  for (int mb = 0; mb < P.M; mb += 8) {
-    float a[4];
-    float b[4][VEC];
+  constexpr int U = 4;   // 32 batch rows per pass: every load of the pass is issued before its MFMAs
+  for (int mb = 0; mb < P.M; mb += 8 * U) {
+    float a[U][4];
+    float b[U][4][VEC];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int m = mb + 4 * h + e;
-      const bool ok = m < P.M;
-      a[e] = ok ? dycol[(size_t)m * P.lddy] : 0.0f;
-      if (ok && kok) {
-        const float* src = xcol + (size_t)m * P.ldx;
-        if constexpr (VEC == 4) {
-          const f32x4 t = *reinterpret_cast<const f32x4*>(src);
-          b[e][0] = t[0]; b[e][1] = t[1]; b[e][2] = t[2]; b[e][3] = t[3];
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = mb + 8 * u + 4 * h + e;
+        const bool ok = m < P.M;
+        a[u][e] = ok ? dycol[(size_t)m * P.lddy] : 0.0f;
+        if (ok && kok) {
+          const float* src = xcol + (size_t)m * P.ldx;
+          if constexpr (VEC == 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(src);
+            b[u][e][0] = t[0]; b[u][e][1] = t[1]; b[u][e][2] = t[2]; b[u][e][3] = t[3];
+          } else {
+            const f32x2 t = *reinterpret_cast<const f32x2*>(src);
+            b[u][e][0] = t[0]; b[u][e][1] = t[1];
+          }
         } else {
-          const f32x2 t = *reinterpret_cast<const f32x2*>(src);
-          b[e][0] = t[0]; b[e][1] = t[1];
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) b[u][e][v] = 0.0f;
         }
-      } else {
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) b[e][v] = 0.0f;
       }
-      dbsum += a[e];
-    }
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) acc[v] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e][v], acc[v], 0, 0, 0);
+      for (int e = 0; e < 4; ++e) {
+        dbsum += a[u][e];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e], b[u][e][v], acc[v], 0, 0, 0);
+      }
   }
 
   if (kok) {

@@ -193,6 +193,8 @@ class ForensicTrainer:
         self.no_improve = 0
         self.ckpt_path = os.path.join(cfg.out_dir, "best.pt")
         self._step_bufs: Dict[Tuple[int, bool], dict] = {}
+        self._enc_bufs: Dict[Tuple[int, int, int], dict] = {}
+        self._enc_stream: Optional[torch.cuda.Stream] = None
 
     # ------------------------------------------------------------------ data
     def _build_dataloaders(self):
@@ -233,8 +235,7 @@ class ForensicTrainer:
     def _load_batch(self, b: dict, batch: Dict[str, torch.Tensor], split: str) -> None:
         """Copy a batch into the static buffers; features come from the cache or from the encoders."""
         if self.cfg.encode_inline and "input_ids" in batch:
-            b["text"].copy_(self.text_encoder(batch["input_ids"], batch["attention_mask"]))
-            b["visual"].copy_(self.visual_encoder(batch["frames"]))
+            self.prefetch_features(batch)
         else:
             b["text"].copy_(batch["text_features"])
             b["visual"].copy_(batch["visual_features"])
@@ -308,13 +309,54 @@ class ForensicTrainer:
                 "forensic": b["forensic"], "logits": b["logits"]}
 
     # ---- software-pipelined variant for encode_inline: all-reduce(i) overlaps encoders(i+1)
+    def _run_encoders(self, e: dict, b: dict) -> None:
+        """text encoder on the current stream, visual encoder on a second stream (two independent
+        chains: the tail / under-filled launches of one are filled by the other), joined at the end."""
+        cur = torch.cuda.current_stream(self.device)
+        if self._enc_stream is None:
+            self._enc_stream = torch.cuda.Stream(device=self.device)
+        side = self._enc_stream
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            b["visual"].copy_(self.visual_encoder(e["frames"]))
+        b["text"].copy_(self.text_encoder(e["ids"], e["mask"]))
+        cur.wait_stream(side)
+
     def prefetch_features(self, batch: Dict[str, torch.Tensor]) -> None:
-        """Run the frozen encoders for `batch` on the compute stream and park the features in the
-        step's static input buffers (stream order keeps them behind the previous step's backward)."""
-        B = int(batch["label"].shape[0])
+        """Run the frozen encoders for `batch` and park the features in the step's static input
+        buffers (stream order keeps them behind the previous step's backward).  With use_graph the
+        two-stream encoder pass (~250 launches) is captured once per shape and replayed."""
+        ids, frames = batch["input_ids"], batch["frames"]
+        if frames.dim() == 4:
+            frames = frames[:, None]
+        B, Lq, Fr = int(ids.shape[0]), int(ids.shape[1]), int(frames.shape[1])
         b = self._bufs(B, True)
-        b["text"].copy_(self.text_encoder(batch["input_ids"], batch["attention_mask"]))
-        b["visual"].copy_(self.visual_encoder(batch["frames"]))
+        key = (B, Lq, Fr)
+        if key not in self._enc_bufs:
+            dev = self.device
+            self._enc_bufs[key] = {"ids": torch.empty(B, Lq, dtype=torch.int64, device=dev),
+                                   "mask": torch.empty(B, Lq, dtype=torch.int32, device=dev),
+                                   "frames": torch.empty(B, Fr, 3, frames.shape[-2], frames.shape[-1], dtype=torch.float32, device=dev),
+                                   "graph": None}
+        e = self._enc_bufs[key]
+        e["ids"].copy_(ids)
+        e["mask"].copy_(batch["attention_mask"])
+        e["frames"].copy_(frames)
+        if not self.cfg.use_graph:
+            self._run_encoders(e, b)
+            return
+        if e["graph"] is None:
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):      # warm-up outside capture: packs weights, allocates buffers
+                self._run_encoders(e, b)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._run_encoders(e, b)
+            e["graph"] = g
+        e["graph"].replay()
 
     def train_step_pipelined(self, batch: Dict[str, torch.Tensor], next_batch: Optional[Dict[str, torch.Tensor]]) -> dict:
         """train_step for raw batches whose encoder features were produced by prefetch_features():
