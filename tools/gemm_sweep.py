@@ -58,14 +58,27 @@ def main():
             err = (ob.float() - ref).abs().max().item()
             assert err <= 0.05 * max(1.0, ref.abs().max().item()), (name, c, err)
         variants = list(cfgs)
+        if "--sched" in sys.argv:
+            for c in cfgs:
+                ob.zero_()
+                run(1000 + c, A, W, bias, ob, M, N, K)
+                torch.cuda.synchronize()
+                err = (ob.float() - ref).abs().max().item()
+                assert err <= 0.05 * max(1.0, ref.abs().max().item()), (name, "sched", c, err)
+            variants += [1000 + c for c in cfgs]
         if ablate:
             variants += [100 + c for c in cfgs] + [200 + c for c in cfgs]
         times = {c: [] for c in variants}
         empty = empty_pair_ms()
+        cold = "--cold" in sys.argv
+        junk = torch.empty(96 << 20, dtype=torch.uint8, device=DEV) if cold else None
         for _ in range(rounds):
             for c in variants:
                 evs = []
+                torch.cuda._sleep(4_000_000)          # let the host run ahead of the GPU
                 for _ in range(8):
+                    if cold:
+                        junk.add_(1)                   # 192 MB of traffic: L2 and part of the MALL turn over
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(); run(c, A, W, bias, ob, M, N, K); e1.record()
                     evs.append((e0, e1))
@@ -76,7 +89,7 @@ def main():
             t = sorted(times[c])
             med = t[len(t) // 2] * 1e-3
             bm, bn, lay = TILES[c % 100]
-            tag = f"{c % 100}:{bm}x{bn}/{lay}" + {0: "", 1: "-noMFMA", 2: "-noDMA"}[c // 100]
+            tag = f"{c % 100}:{bm}x{bn}/{lay}" + {0: "", 1: "-noMFMA", 2: "-noDMA"}[(c % 1000) // 100] + ("-sched" if c >= 1000 else "")
             tiles = -(-M // bm) * (N // bn)
             row[tag] = {"us": round(med * 1e6, 2), "tflops": round(2.0 * M * N * K / med / 1e12, 1), "tiles": tiles}
         out[name] = row

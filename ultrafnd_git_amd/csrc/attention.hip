@@ -2,7 +2,7 @@
 // (BertSelfAttention eager path / CLIPAttention; head_dim 64, 12 heads in both encoders.)
 //
 // One workgroup = one (batch, head, 128-query block); wave w owns 32 queries.  Keys/values are
-// walked in blocks of 128 with an online softmax, so L = 50 (ViT), 128 and 512 (BERT) share
+// walked in blocks of 64 with an online softmax, so L = 50 (ViT), 128 and 512 (BERT) share
 // the code and nothing of size L x L ever exists.
 //
 // MFMA orientation (v_mfma_f32_16x16x32_bf16; C/D: column = lane & 15, row = 4*(lane>>4)+r):
@@ -20,7 +20,6 @@
 
 namespace {
 
-constexpr int KB = 128;          // keys per block
 constexpr int QB = 128;          // queries per workgroup
 constexpr float NEG_MASK = -3.0e38f;
 
@@ -28,6 +27,8 @@ __device__ __forceinline__ bf16x8 k_frag(const char* tile, int row, int chunk) {
   return *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
 }
 
+// KB = keys per block (64: ~216 registers -> two workgroups per CU; 128: fewer softmax rescales)
+template <int KB>
 __global__ __launch_bounds__(256) void attention_kernel(const __bf16* qkv, const int32_t* mask, __bf16* ctx, int L,
                                                         int heads, float scale_log2e) {
   __shared__ __attribute__((aligned(16))) char ks[KB * 128];
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const __bf16* qkv, const
     __syncthreads();  // previous block's LDS reads are done
     // ---- stage K and V tiles (row-major 128-B rows, swizzled 16-B chunks) and the key bias
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < KB / 32; ++it) {
       const int idx = tid + 256 * it, key = idx >> 3, c = idx & 7;
       const int kr = (kb0 + key) < L ? (kb0 + key) : L - 1;
       const __bf16* src = qkv + (tok0 + kr) * ld + H + h * 64 + c * 8;
@@ -81,27 +82,28 @@ __global__ __launch_bounds__(256) void attention_kernel(const __bf16* qkv, const
     __syncthreads();
 
     // ---- S^T = K Q^T : 8 key tiles x 2 query tiles
-    f32x4 s[8][2];
+    constexpr int KT = KB / 16;
+    f32x4 s[KT][2];
 #pragma unroll
-    for (int kt = 0; kt < 8; ++kt)
+    for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) s[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int kt = 0; kt < 8; ++kt) {
+      for (int kt = 0; kt < KT; ++kt) {
         const bf16x8 kf = k_frag(ks, kt * 16 + fr, g + 4 * kk);
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][kk], s[kt][qt], 0, 0, 0);
       }
 
     // ---- online softmax (scores kept in the log2 domain: exp(x) = exp2(x * log2 e))
-    bf16x8 pf[4][2];
+    bf16x8 pf[KT / 2][2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       float mx = -INFINITY;
 #pragma unroll
-      for (int kt = 0; kt < 8; ++kt) {
+      for (int kt = 0; kt < KT; ++kt) {
         const f32x4 kbv = *reinterpret_cast<const f32x4*>(kbias + kt * 16 + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const __bf16* qkv, const
       const float alpha = exp2f(m_run[qt] - m_new);    // first block: exp2(-inf) = 0
       float lsum = 0.0f;
 #pragma unroll
-      for (int kt = 0; kt < 8; ++kt)
+      for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float p = exp2f(s[kt][qt][r] - m_new);
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const __bf16* qkv, const
 
     // ---- O^T += V^T P^T : contraction over the block's 128 keys in 4 steps of 32
 #pragma unroll
-    for (int ksd = 0; ksd < 4; ++ksd) {
+    for (int ksd = 0; ksd < KT / 2; ++ksd) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         // hardware-transposed read: 16-lane group g, lane 4q+p supplies &V[key][16dt + 4p]
@@ -180,7 +182,7 @@ extern "C" int ufnd_attention_bf16(const void* qkv, const int32_t* key_mask, voi
   UFND_REQUIRE(ufnd_aligned(qkv, 16) && ufnd_aligned(ctx, 16), "attention: 16-B alignment required");
   UFND_REQUIRE(B <= 65535, "attention: B too large for grid.z");
   const float scale_log2e = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) * log2(e)
-  hipLaunchKernelGGL(attention_kernel, dim3(ufnd_cdiv(L, QB), heads, B), dim3(256), 0, (hipStream_t)stream_,
+  hipLaunchKernelGGL(attention_kernel<64>, dim3(ufnd_cdiv(L, QB), heads, B), dim3(256), 0, (hipStream_t)stream_,
                      (const __bf16*)qkv, key_mask, (__bf16*)ctx, L, heads, scale_log2e);
   UFND_CHECK_LAUNCH();
   return UFND_OK;

@@ -52,7 +52,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 //            (everyone's pieces landed, and everyone is done reading stage t-1)  ->  issue stage
 //            t+ST-1 into the buffer stage t-1 used  ->  multiply stage t.
 // ABL (timing experiments only, results are garbage): 1 = no MFMA/LDS reads, 2 = no DMA in the loop
-template <int BM, int BN, int WM, int WN, int ST, int ABL = 0>
+// SCH: 0 = compiler's schedule; 1 = explicit: both k-halves' fragment reads issued first (the second
+// half lands while the first half multiplies), then the stage's DMA pieces spread between MFMA groups.
+template <int BM, int BN, int WM, int WN, int ST, int ABL = 0, int SCH = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs a) {
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN;      // wave tile
@@ -118,20 +120,48 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (ABL != 2 && t + ST - 1 < nk) issue(t + ST - 1);
     const char* At = smem + (t % ST) * STAGE;
     const char* Bt = At + BM * 128;
+    if constexpr (SCH == 0 || ABL != 0) {
+      if (ABL != 2 && t + ST - 1 < nk) issue(t + ST - 1);
 #pragma unroll
-    for (int kk = 0; kk < (ABL == 1 ? 0 : 2); ++kk) {
-      bf16x8 af[MT], bfr[NT];
+      for (int kk = 0; kk < (ABL == 1 ? 0 : 2); ++kk) {
+        bf16x8 af[MT], bfr[NT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = lds_frag(At, wm * TM + i * 16 + fr, g + 4 * kk);
+        for (int i = 0; i < MT; ++i) af[i] = lds_frag(At, wm * TM + i * 16 + fr, g + 4 * kk);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bfr[j] = lds_frag(Bt, wn * TN + j * 16 + fr, g + 4 * kk);
+        for (int j = 0; j < NT; ++j) bfr[j] = lds_frag(Bt, wn * TN + j * 16 + fr, g + 4 * kk);
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+      bf16x8 af[2][MT], bfr[2][NT];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[kk][i] = lds_frag(At, wm * TM + i * 16 + fr, g + 4 * kk);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bfr[kk][j] = lds_frag(Bt, wn * TN + j * 16 + fr, g + 4 * kk);
+      }
+      if (t + ST - 1 < nk) issue(t + ST - 1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
+      // shape of the emitted stream: all 2(MT+NT) LDS reads, then {G MFMAs, 1 DMA piece} x PW, then the rest
+      constexpr int NMF = 2 * MT * NT, GRP = NMF / (PW + 1) > 0 ? NMF / (PW + 1) : 1;
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MT + NT), 0);
+#pragma unroll
+      for (int q = 0; q < PW; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, GRP, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, NMF - GRP * PW > 0 ? NMF - GRP * PW : 0, 0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this step's LDS reads retired before the next barrier
   }
@@ -238,14 +268,15 @@ static const TileCfg kTiles[] = {
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
-static int launch_cfg(int cfg, int abl, GemmArgs& a, hipStream_t stream) {
+static int launch_cfg(int cfg, int abl, int sch, GemmArgs& a, hipStream_t stream) {
   const TileCfg& t = kTiles[cfg];
   a.m_tiles = ufnd_cdiv(a.M, t.bm);
   a.n_tiles = a.N / t.bn;
   const dim3 grid(a.m_tiles * a.n_tiles), block(t.threads);
 #define GO(BM_, BN_, WM_, WN_, ST_)                                                                               \
   do {                                                                                                              \
-    if (abl == 0) hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, ST_, 0>), grid, block, 0, stream, a);   \
+    if (abl == 0 && sch == 1) hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, ST_, 0, 1>), grid, block, 0, stream, a); \
+    else if (abl == 0) hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, ST_, 0>), grid, block, 0, stream, a);   \
     else if (abl == 1) hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, ST_, 1>), grid, block, 0, stream, a); \
     else hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, ST_, 2>), grid, block, 0, stream, a);           \
   } while (0)
@@ -292,7 +323,9 @@ static int auto_cfg(int M, int N, int K) {
     if (N % 96 == 0 && tiles(12) >= 400) return 12;    //   64x96 4-stage, 2 blocks/CU
     return 20;                                         //   128x64 8 waves 4-stage
   }
-  return 1;                                            // 128x64 3-stage, 2 blocks/CU (out-proj)
+  if (N % 128 == 0 && tiles(16) >= 150) return 16;     // out-proj at M=4096: 128x128 8 waves
+  if (N % 96 == 0) return 12;                          // small out-proj: 64x96
+  return 1;                                            // 128x64 3-stage, 2 blocks/CU
 }
 
 extern "C" int ufnd_gemm_bf16_ex(const void* A, const void* W, const float* bias, const float* residual, void* out_bf16,
@@ -309,11 +342,13 @@ extern "C" int ufnd_gemm_bf16_ex(const void* A, const void* W, const float* bias
   UFND_REQUIRE(act >= 0 && act <= 2, "gemm_bf16: act=%d", act);
   GemmArgs a{(const __bf16*)A, (const __bf16*)W, bias, residual, (__bf16*)out_bf16, out_f32, M, N, K, lda, ldw, ldr, ldo, ldf, act, 0, 0};
   // tile_cfg >= 0: explicit tile; +100 / +200 select the timing-only ablations (no MFMA / no in-loop DMA)
-  int abl = 0, cfg = tile_cfg < 0 ? auto_cfg(M, N, K) : tile_cfg;
+  // automatic choice uses the explicit software-pipelined schedule (5-12 % faster on every shape swept)
+  int abl = 0, sch = tile_cfg < 0 ? 1 : 0, cfg = tile_cfg < 0 ? auto_cfg(M, N, K) : tile_cfg;
+  if (cfg >= 1000) { sch = 1; cfg -= 1000; }       // +1000: explicit software-pipelined schedule
   if (cfg >= 200) { abl = 2; cfg -= 200; } else if (cfg >= 100) { abl = 1; cfg -= 100; }
   UFND_REQUIRE(cfg < kNumTiles, "gemm_bf16: unknown tile config %d", cfg);
   UFND_REQUIRE(N % kTiles[cfg].bn == 0, "gemm_bf16: tile config %d needs N %% %d == 0", cfg, kTiles[cfg].bn);
-  int rc = launch_cfg(cfg, abl, a, (hipStream_t)stream_);
+  int rc = launch_cfg(cfg, abl, sch, a, (hipStream_t)stream_);
   if (rc != UFND_OK) return rc;
   UFND_CHECK_LAUNCH();
   return UFND_OK;

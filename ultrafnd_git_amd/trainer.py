@@ -192,9 +192,12 @@ class ForensicTrainer:
         self.best_val_auc = -1.0
         self.no_improve = 0
         self.ckpt_path = os.path.join(cfg.out_dir, "best.pt")
-        self._step_bufs: Dict[Tuple[int, bool], dict] = {}
+        self._step_bufs: Dict[Tuple[int, bool, int], dict] = {}
         self._enc_bufs: Dict[Tuple[int, int, int], dict] = {}
-        self._enc_stream: Optional[torch.cuda.Stream] = None
+        self._enc_streams = None
+        self._slot = 0
+        self._feat_ready = [None, None]
+        self._slot_free = [None, None]
 
     # ------------------------------------------------------------------ data
     def _build_dataloaders(self):
@@ -210,15 +213,18 @@ class ForensicTrainer:
         return {"train": self.train_loader, "val": self.val_loader}.get(split, self.test_loader).dataset
 
     # ------------------------------------------------------------------ the step
-    def _bufs(self, B: int, train: bool) -> dict:
-        """Static buffers of one batch size (graph replay needs fixed addresses)."""
-        key = (B, train)
+    def _bufs(self, B: int, train: bool, slot: int = 0) -> dict:
+        """Static buffers of one batch size (graph replay needs fixed addresses).  Two slots exist so
+        that the encoders can fill step i+1's inputs while step i's backward still reads its own."""
+        key = (B, train, slot)
         if key not in self._step_bufs:
             dev, f32 = self.device, torch.float32
             dims = self.clf.dims()
             dims.fusion_dropout = self.fusion.dropout
-            fws = self.fusion.workspace(B, train)
-            cws = self.clf.workspace(B, train)
+            n_f = L.lib().ufnd_fusion_workspace_floats(C.byref(dims), B)
+            n_c = L.lib().ufnd_clf_workspace_floats(C.byref(dims), B)
+            fws = torch.empty(n_f, dtype=f32, device=dev)
+            cws = torch.empty(n_c, dtype=f32, device=dev)
             ld = C.c_int(0)
             xin = L.lib().ufnd_clf_input_panel(C.byref(dims), cws.data_ptr(), B, C.byref(ld))
             self._step_bufs[key] = {
@@ -235,7 +241,10 @@ class ForensicTrainer:
     def _load_batch(self, b: dict, batch: Dict[str, torch.Tensor], split: str) -> None:
         """Copy a batch into the static buffers; features come from the cache or from the encoders."""
         if self.cfg.encode_inline and "input_ids" in batch:
-            self.prefetch_features(batch)
+            self.prefetch_features(batch, 0)
+            for ev in self._feat_ready[0]:
+                torch.cuda.current_stream(self.device).wait_event(ev)
+            self._feat_ready[0] = None
         else:
             b["text"].copy_(batch["text_features"])
             b["visual"].copy_(batch["visual_features"])
@@ -309,70 +318,110 @@ class ForensicTrainer:
                 "forensic": b["forensic"], "logits": b["logits"]}
 
     # ---- software-pipelined variant for encode_inline: all-reduce(i) overlaps encoders(i+1)
-    def _run_encoders(self, e: dict, b: dict) -> None:
-        """text encoder on the current stream, visual encoder on a second stream (two independent
-        chains: the tail / under-filled launches of one are filled by the other), joined at the end."""
-        cur = torch.cuda.current_stream(self.device)
-        if self._enc_stream is None:
-            self._enc_stream = torch.cuda.Stream(device=self.device)
-        side = self._enc_stream
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            b["visual"].copy_(self.visual_encoder(e["frames"]))
-        b["text"].copy_(self.text_encoder(e["ids"], e["mask"]))
-        cur.wait_stream(side)
+    # ---- encoders: two independent chains on two streams, each captured as its own hipGraph
+    def _enc_state(self, B: int, Lq: int, Fr: int, S: int) -> dict:
+        key = (B, Lq, Fr)
+        if key not in self._enc_bufs:
+            dev = self.device
+            self._enc_bufs[key] = {
+                "ids": torch.empty(B, Lq, dtype=torch.int64, device=dev), "mask": torch.empty(B, Lq, dtype=torch.int32, device=dev),
+                "frames": torch.empty(B, Fr, 3, S, S, dtype=torch.float32, device=dev),
+                "text_out": torch.empty(B, 768, dtype=torch.float32, device=dev),
+                "vis_out": torch.empty(B, 512, dtype=torch.float32, device=dev), "g_text": None, "g_vis": None}
+        if self._enc_streams is None:
+            self._enc_streams = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
+        return self._enc_bufs[key]
 
-    def prefetch_features(self, batch: Dict[str, torch.Tensor]) -> None:
-        """Run the frozen encoders for `batch` and park the features in the step's static input
-        buffers (stream order keeps them behind the previous step's backward).  With use_graph the
-        two-stream encoder pass (~250 launches) is captured once per shape and replayed."""
+    def _encode_text(self, e: dict) -> None:
+        e["text_out"].copy_(self.text_encoder(e["ids"], e["mask"]))
+
+    def _encode_vis(self, e: dict) -> None:
+        e["vis_out"].copy_(self.visual_encoder(e["frames"]))
+
+    def _replay_or_capture(self, e: dict, which: str, fn) -> None:
+        """Run `fn(e)` on the current stream: eagerly, or (use_graph) from a graph captured once."""
+        if not self.cfg.use_graph:
+            fn(e)
+            return
+        if e[which] is None:
+            fn(e)                                   # warm-up: packs weights, allocates buffers
+            torch.cuda.current_stream(self.device).synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=torch.cuda.current_stream(self.device)):
+                fn(e)
+            e[which] = g
+        e[which].replay()
+
+    def prefetch_features(self, batch: Dict[str, torch.Tensor], slot: Optional[int] = None,
+                          inputs_ready: Optional[torch.cuda.Event] = None) -> None:
+        """Encode `batch` on the two encoder streams (text || visual) into input slot `slot` of the step
+        buffers.  Runs concurrently with whatever the compute stream is doing (the fusion head of the
+        previous batch); `_feat_ready[slot]` is recorded when both features have landed."""
+        slot = self._slot if slot is None else slot
         ids, frames = batch["input_ids"], batch["frames"]
         if frames.dim() == 4:
             frames = frames[:, None]
         B, Lq, Fr = int(ids.shape[0]), int(ids.shape[1]), int(frames.shape[1])
-        b = self._bufs(B, True)
-        key = (B, Lq, Fr)
-        if key not in self._enc_bufs:
-            dev = self.device
-            self._enc_bufs[key] = {"ids": torch.empty(B, Lq, dtype=torch.int64, device=dev),
-                                   "mask": torch.empty(B, Lq, dtype=torch.int32, device=dev),
-                                   "frames": torch.empty(B, Fr, 3, frames.shape[-2], frames.shape[-1], dtype=torch.float32, device=dev),
-                                   "graph": None}
-        e = self._enc_bufs[key]
-        e["ids"].copy_(ids)
-        e["mask"].copy_(batch["attention_mask"])
-        e["frames"].copy_(frames)
-        if not self.cfg.use_graph:
-            self._run_encoders(e, b)
-            return
-        if e["graph"] is None:
-            side = torch.cuda.Stream(device=self.device)
-            side.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(side):      # warm-up outside capture: packs weights, allocates buffers
-                self._run_encoders(e, b)
-            torch.cuda.current_stream(self.device).wait_stream(side)
-            torch.cuda.synchronize(self.device)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._run_encoders(e, b)
-            e["graph"] = g
-        e["graph"].replay()
+        b = self._bufs(B, True, slot)
+        e = self._enc_state(B, Lq, Fr, int(frames.shape[-1]))
+        main = torch.cuda.current_stream(self.device)
+        st, sv = self._enc_streams
+        for strm in (st, sv):
+            # the batch tensors were produced on the compute stream: wait for THEM, not for later work
+            if inputs_ready is not None:
+                strm.wait_event(inputs_ready)
+            else:
+                strm.wait_stream(main)
+            if self._slot_free[slot] is not None:
+                strm.wait_event(self._slot_free[slot])   # the head that last used this slot is done with it
+        with torch.cuda.stream(st):
+            e["ids"].copy_(ids)
+            e["mask"].copy_(batch["attention_mask"])
+            self._replay_or_capture(e, "g_text", self._encode_text)
+            b["text"].copy_(e["text_out"])
+            ev_t = torch.cuda.Event()
+            ev_t.record(st)
+        with torch.cuda.stream(sv):
+            e["frames"].copy_(frames)
+            self._replay_or_capture(e, "g_vis", self._encode_vis)
+            b["visual"].copy_(e["vis_out"])
+            ev_v = torch.cuda.Event()
+            ev_v.record(sv)
+        for t in (ids, batch["attention_mask"], frames):
+            t.record_stream(st)
+            t.record_stream(sv)
+        self._feat_ready[slot] = (ev_t, ev_v)
 
     def train_step_pipelined(self, batch: Dict[str, torch.Tensor], next_batch: Optional[Dict[str, torch.Tensor]]) -> dict:
-        """train_step for raw batches whose encoder features were produced by prefetch_features():
-        fwd/bwd(i) -> start all-reduce(i) on the comm stream -> encoders(i+1) on the compute stream
-        -> wait -> clip + AdamW(i).  Same arithmetic and order of parameter updates as train_step."""
+        """train_step for raw batches whose features were started by prefetch_features():
+          compute stream : wait features(i) -> head fwd/bwd(i) -> [all-reduce(i)] -> clip + AdamW(i)
+          encoder streams: text(i+1) || visual(i+1), launched right after the head of i is enqueued
+        so the head, the exchange and the optimizer of step i all hide behind the (frozen) encoders of
+        step i+1.  Same arithmetic and order of parameter updates as train_step (bit-identical)."""
         B = int(batch["label"].shape[0])
-        b = self._bufs(B, True)
+        slot = self._slot
+        b = self._bufs(B, True, slot)
+        main = torch.cuda.current_stream(self.device)
+        if self._feat_ready[slot] is None:
+            raise RuntimeError("train_step_pipelined: call prefetch_features(batch) for the first batch")
+        inputs_ready = torch.cuda.Event()
+        inputs_ready.record(main)                  # next_batch (if any) exists on the device by now
+        for ev in self._feat_ready[slot]:
+            main.wait_event(ev)
+        self._feat_ready[slot] = None
         for k_src, k_dst in (("audio_features", "audio"), ("temporal_features", "temporal"), ("aux", "aux"),
                              ("label", "label"), ("gnn_feat", "gnn")):
             b[k_dst].copy_(batch[k_src])
         self._fwd_bwd(b, B)
+        done = torch.cuda.Event()
+        done.record(main)
+        self._slot_free[slot] = done
         self.reducer.start()
         if next_batch is not None:
-            self.prefetch_features(next_batch)
+            self.prefetch_features(next_batch, slot ^ 1, inputs_ready)
         self.reducer.finish()
         self.optim.clip_and_step()
+        self._slot ^= 1
         return {"loss": self.optim.state.float_view("loss"), "probs": b["probs"], "y": b["label"],
                 "forensic": b["forensic"], "logits": b["logits"]}
 
@@ -394,7 +443,11 @@ class ForensicTrainer:
             enc._gemm = timed
         try:
             for _ in range(steps):
+                # park the GPU behind a ~4 ms spin so the host has every launch and event of the pass queued
+                # before the GPU reaches them: event deltas then measure GPU time, not host enqueue latency
+                torch.cuda._sleep(8_000_000)
                 self.text_encoder(batch["input_ids"], batch["attention_mask"])
+                torch.cuda._sleep(8_000_000)
                 self.visual_encoder(batch["frames"])
             torch.cuda.synchronize(self.device)
         finally:
