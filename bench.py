@@ -7,7 +7,8 @@
 One "step" = one pass of the hot path over one synthetic FakeSV batch (BASELINE.json configs[1]:
 full model, batch 32 per GPU, seq_len 128, one 224x224 frame), inputs resident in HBM:
   BERT-base text encoder fwd (bf16 MFMA) + ViT-B/32 visual encoder fwd (bf16 MFMA) -> pooled
-  features -> CrossModalTransformer + DeepTruthClassifier fwd (train-mode dropout) -> CE ->
+  features (+ temporal = TemporalSyncNet.align(text, visual)) -> CrossModalTransformer +
+  DeepTruthClassifier fwd (train-mode dropout) -> CE ->
   backward -> [RCCL all-reduce] -> clip_grad_norm_(5) -> AdamW.   (encoders frozen, as in the
   reference; nothing is cached or skipped inside the timed region.)
 Prints ONE JSON line (rank 0) with the contract's fields plus `roofline` (the bf16 GEMM kernel,
@@ -107,13 +108,15 @@ def main():
         raise SystemExit("bench.py needs a HIP device (MI355X); there is no CPU path to time as the product")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ      # started by torch.distributed.run
+    if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
     if args.gpus != world and rank == 0:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: using {world}", file=sys.stderr)
 
     from ultrafnd_git_amd.encoders import BertTextEncoder, ClipVisualEncoder
+    from ultrafnd_git_amd.temporal import TemporalSyncNet
     from ultrafnd_git_amd.trainer import ForensicTrainer, TrainConfig, synthetic_cache
 
     B = args.batch
@@ -122,7 +125,8 @@ def main():
     venc = ClipVisualEncoder().to(dev)          # CLIP ViT-B/32 geometry, random init
     cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir="/tmp/ufnd_bench", batch_size=B, device=str(dev),
                       use_graph=not args.no_graph, encode_inline=True, seed=42)
-    tr = ForensicTrainer(cfg, cache=synthetic_cache(64, seed=1), text_encoder=tenc, visual_encoder=venc)
+    tsync = TemporalSyncNet(in_dim=768, out_dim=256).to(dev)   # temporal = align(text, visual), as the cache builder does
+    tr = ForensicTrainer(cfg, cache=synthetic_cache(64, seed=1), text_encoder=tenc, visual_encoder=venc, temporal_net=tsync)
     tr.fusion.train()
     tr.clf.train()
     batches = make_batches(B, 4, 42 + 2 + 1000 * rank, dev)
@@ -135,7 +139,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -145,7 +149,7 @@ def main():
     run(args.steps)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -161,7 +165,10 @@ def main():
         roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
                 "launches_per_step": n_launch, "avg_launch_us": round(gem_ms * 1e3 / n_launch, 2),
-                "gemm_ms_per_step": round(gem_ms, 4), "flops_per_launch_avg": flops / n_launch}
+                "gemm_ms_per_step": round(gem_ms, 4), "flops_per_launch_avg": flops / n_launch,
+                "by_shape_MxNxK": {k: {"launches_per_step": v[0] // 3, "avg_us": round(v[1] / v[0] * 1e3, 2),
+                                       "tflops": round(2.0 * eval(k.replace("x", "*")) / (v[1] / v[0] * 1e-3) / 1e12, 1)}
+                                   for k, v in tr.last_gemm_by_shape.items()}}
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(B)
@@ -177,7 +184,7 @@ def main():
                        "encoder_dtype": "bf16 operands / fp32 accumulate", "head_dtype": "fp32", "hip_graph": not args.no_graph,
                        "weights": "random init of the named architectures"},
             "final_loss": final_loss, "roofline": roof, "cpu_baseline": cpu}))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -229,6 +229,12 @@ int ufnd_bert_embed(const int64_t* ids, const float* word, const float* pos, con
 int ufnd_masked_meanpool_l2(const float* hidden, const int32_t* mask, float* out, int B, int L, int H,
                             void* stream);
 
+/* BERTContextEncoder.encode_fields (text_blocks.py:108-128): parts (N, M, D) fp32 are the encoded
+ * title / OCR / comment vectors of N records, valid (N, M) int32 marks the parts that exist
+ * (empty strings are skipped by the reference); out (N, D) = mean of the valid parts, then
+ * v / (||v|| + 1e-9); zero vector when a record has no part. */
+int ufnd_field_mean_l2(const float* parts, const int32_t* valid, float* out, int N, int M, int D, void* stream);
+
 /* CLIP patch embedding as an im2col-free GEMM operand: frames (N,3,S,S) fp32 ->
  * patches (N*(S/P)^2, 3*P*P) bf16 in the conv weight's (c,ky,kx) order. */
 int ufnd_vit_patchify(const float* frames, void* patches_bf16, int N, int image, int patch, void* stream);
@@ -240,6 +246,19 @@ int ufnd_vit_assemble(const float* patch_emb, const float* cls, const float* pos
 /* per-frame e / (||e|| + 1e-9); then, for F > 1, mean over the F frames of a sample and
  * L2-normalise again (text_blocks.py:126-128 idiom).  e (B*F, D) fp32 -> out (B, D). */
 int ufnd_l2norm_frames(const float* e, float* out, int B, int F, int D, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * TemporalSyncNet.align, batched          src/core_blocks/temporal_blocks.py:102-140 (+ _cosine :10-13)
+ *   text (B,D), visual (B,Dv) fp32 -> out (B,out_dim): W3 GELU(W0 [t, v^, t-v^, t*v^, cos] + b0) + b3
+ *   with v^ = visual zero-padded / truncated to D.  w0 is (hidden, 4D+1) stored with row stride
+ *   ufnd_temporal_weight_ld(D) (4D+1 rounded up to a multiple of 4, pad zero); w3 (out_dim, hidden).
+ *   workspace: ufnd_temporal_workspace_floats(B, D, hidden) floats.
+ * ---------------------------------------------------------------------------------- */
+int ufnd_temporal_weight_ld(int in_dim);
+size_t ufnd_temporal_workspace_floats(int B, int in_dim, int hidden);
+int ufnd_temporal_align(const float* text, const float* visual, const float* w0, const float* b0, const float* w3,
+                        const float* b3, float* workspace, float* out, int B, int in_dim, int vis_dim, int hidden,
+                        int out_dim, void* stream);
 
 #ifdef __cplusplus
 }

@@ -15,6 +15,7 @@ What it does
            element-for-element, and stores the reference's outputs (full for the small
            tensors, per-tensor digests for grads/params) in tier_a_B*.npz.
   metrics  runs the reference's forensic_metrics on known inputs -> metrics_kat.json.
+  temporal runs the reference's TemporalSyncNet.align on seeded weights -> temporal.npz.
   tier_b   builds the locally installed third-party BertModel / CLIPVisionModelWithProjection
            from local configs (2 layers, small vocab; no from_pretrained), loads
            oracle.encoders_ref.seeded_weights, stores inputs + outputs in tier_b.npz and
@@ -291,10 +292,36 @@ def tier_b():
     np.savez_compressed(HERE / "tier_b.npz", **store)
 
 
+def temporal():
+    """TemporalSyncNet.align (src/core_blocks/temporal_blocks.py:102-140) with seeded weights."""
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, str(REF))
+    from src.core_blocks.temporal_blocks import TemporalSyncNet
+    from oracle import temporal_ref as T
+    w = T.seeded_weights(51)
+    net = TemporalSyncNet(in_dim=768, out_dim=256).to("cpu").eval()
+    assert list(net.state_dict().keys()) == list(w.keys())
+    net.load_state_dict(w)
+    g = torch.Generator().manual_seed(52)
+    t = torch.randn(6, 768, generator=g)
+    t = t / t.norm(dim=1, keepdim=True)
+    v = torch.randn(6, 512, generator=g)
+    v = v / v.norm(dim=1, keepdim=True)
+    v[5] = 0                                             # zero visual vector: cosine's eps path
+    ref = torch.stack([torch.from_numpy(net.align(t[i].numpy(), v[i].numpy())) for i in range(6)])
+    ref_self = torch.from_numpy(net.align(t[0].numpy(), t[0].numpy()))      # fakesv_dataset.py:180 usage
+    ora = T.align(w, t, v)
+    assert (ref - ora).abs().max().item() <= 1e-6
+    assert (ref_self - T.align(w, t[:1], t[:1])[0]).abs().max().item() <= 1e-6
+    np.savez_compressed(HERE / "temporal.npz", weight_seed=np.int64(51), t=t.numpy(), v=v.numpy(), out=ref.numpy(),
+                        out_self=ref_self.numpy(), checksum=np.float64(sum(x.double().sum() for x in w.values())))
+    print("temporal: oracle-vs-reference max-abs-err", (ref - ora).abs().max().item())
+
+
 if __name__ == "__main__":
     part = sys.argv[1] if len(sys.argv) > 1 else "all"
     if part == "all":
-        for p in ("tier_a", "metrics", "tier_b"):
+        for p in ("tier_a", "metrics", "tier_b", "temporal"):
             subprocess.check_call([sys.executable, str(Path(__file__).resolve()), p], cwd=str(REPO))
     else:
-        {"tier_a": tier_a, "metrics": metrics, "tier_b": tier_b}[part]()
+        {"tier_a": tier_a, "metrics": metrics, "tier_b": tier_b, "temporal": temporal}[part]()

@@ -185,3 +185,21 @@ def test_cpu_use_fails_loudly():
     m = CrossModalTransformer()
     with pytest.raises(UltrafndHipError):
         m({k: torch.zeros(2, d) for k, d in zip(FEATS, (768, 128, 512, 256, 128))})
+
+
+def test_temporal_align_matches_reference():
+    """TemporalSyncNet.align on the HIP path vs the reference's outputs (tests/golden/temporal.npz); fp32, 2e-6."""
+    from oracle import temporal_ref as T
+    from ultrafnd_git_amd.temporal import TemporalSyncNet
+    z = load_npz("temporal.npz")
+    net = TemporalSyncNet(in_dim=768, out_dim=256)
+    net.load_state_dict(T.seeded_weights(int(z["weight_seed"])))
+    net = net.to("cuda")
+    t, v = torch.from_numpy(z["t"]), torch.from_numpy(z["v"])
+    got = net.align_batch(t, v).cpu().numpy()
+    err = np.abs(got - z["out"]).max()
+    one = net.align(z["t"][0], z["t"][0])
+    print("temporal align max-abs-err", err)
+    assert err <= 2e-6 and np.abs(one - z["out_self"]).max() <= 2e-6 and one.dtype == np.float32
+    wide = net.align_batch(t, torch.cat([torch.from_numpy(z["t"]), torch.ones(6, 40)], dim=1))    # Dv > D: truncated
+    assert np.abs(wide.cpu().numpy() - T.align(T.seeded_weights(51), t, t).numpy()).max() <= 2e-6

@@ -162,6 +162,34 @@ def test_visual_features_match_third_party(tag):
     assert ef <= 4e-3, ef
 
 
+def test_encode_fields_batched():
+    """encode_fields: title + OCR + <=10 comments per record, empty parts skipped, record without parts -> 0."""
+    from oracle import encoders_ref as E
+    from ultrafnd_git_amd.encoders import BertTextEncoder
+    w = E.seeded_weights(E.bert_shapes(layers=2, vocab=1000), 21)
+    enc = BertTextEncoder(layers=2, vocab_size=1000)
+    enc.load_state_dict(w)
+    enc = enc.to(DEV)
+    N, Mx, Lq = 5, 12, 24
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, 1000, (N, Mx, Lq), generator=g)
+    lens = torch.randint(1, Lq + 1, (N, Mx), generator=g)
+    mask = (torch.arange(Lq)[None, None] < lens[..., None]).long()
+    valid = (torch.rand(N, Mx, generator=g) < 0.6).long()
+    valid[1] = 0                                           # a record with no title / OCR / comments
+    valid[2] = 1                                           # a record with all 12 parts
+    got = enc.encode_fields(ids, mask, valid).cpu()
+    ref = torch.zeros(N, 768)
+    for n in range(N):
+        sel = valid[n].bool()
+        if sel.any():
+            ref[n] = E.field_mean_l2(E.text_features(w, ids[n][sel], mask[n][sel]))
+    err = (got - ref).abs().max().item()
+    print(f"encode_fields max-abs-err {err:.3e}")
+    assert got[1].abs().max().item() == 0.0
+    assert err <= 4e-3, err
+
+
 def test_full_depth_encoders_vs_oracle():
     """12-layer BERT-base / ViT-B/32 geometry (small vocab to keep the CPU oracle quick)."""
     from oracle import encoders_ref as E

@@ -41,3 +41,14 @@ def test_pooling_edge_cases():
     assert torch.isfinite(f).all() and f[1].abs().max() == 0
     assert abs(f[0].norm().item() - 1.0) < 1e-5
     assert torch.allclose(E.field_mean_l2(f[None, :1]), f[:1], atol=1e-6)
+
+
+def test_temporal_align_matches_reference():
+    """oracle/temporal_ref.py vs the reference's TemporalSyncNet.align outputs (tests/golden/temporal.npz)."""
+    from oracle import temporal_ref as T
+    z = load_npz("temporal.npz")
+    w = T.seeded_weights(int(z["weight_seed"]))
+    assert abs(float(sum(x.double().sum() for x in w.values())) - float(z["checksum"])) < 1e-9
+    t, v = torch.from_numpy(z["t"]), torch.from_numpy(z["v"])
+    assert np.abs(T.align(w, t, v).numpy() - z["out"]).max() <= 1e-6
+    assert np.abs(T.align(w, t[:1], t[:1])[0].numpy() - z["out_self"]).max() <= 1e-6

@@ -94,11 +94,17 @@ def _declare_encoders(lib: C.CDLL) -> None:
         "ufnd_vit_patchify": [P, P, I, I, I, P],
         "ufnd_vit_assemble": [P] * 6 + [I, I, I, F, P],
         "ufnd_l2norm_frames": [P, P, I, I, I, P],
+        "ufnd_field_mean_l2": [P, P, P, I, I, I, P],
+        "ufnd_temporal_align": [P] * 8 + [I] * 5 + [P],
     }
     for name, argtypes in sigs.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = I
+    lib.ufnd_temporal_weight_ld.argtypes = [I]
+    lib.ufnd_temporal_weight_ld.restype = I
+    lib.ufnd_temporal_workspace_floats.argtypes = [I, I, I]
+    lib.ufnd_temporal_workspace_floats.restype = S
 
 
 def lib() -> C.CDLL:

@@ -188,6 +188,35 @@ __global__ __launch_bounds__(256) void l2norm_frames_kernel(const float* e, floa
   for (int c = threadIdx.x; c < D; c += 256, ++n) out[(size_t)b * D + c] = acc[n] / nrm;
 }
 
+// encode_fields (text_blocks.py:108-128): mean of the VALID part vectors of a record, then
+// v / (||v|| + 1e-9); a record without parts yields the zero vector.  One block per record.
+__global__ __launch_bounds__(256) void field_mean_l2_kernel(const float* parts, const int32_t* valid, float* out, int Mx,
+                                                            int D) {
+  __shared__ float sh[4];
+  const int n = blockIdx.x;
+  float acc[4] = {0, 0, 0, 0};
+  int cnt = 0;
+  for (int m = 0; m < Mx; ++m) {
+    if (valid[(size_t)n * Mx + m] == 0) continue;
+    ++cnt;
+    const float* row = parts + ((size_t)n * Mx + m) * D;
+    int k = 0;
+    for (int c = threadIdx.x; c < D; c += 256, ++k) acc[k] += row[c];
+  }
+  float sq = 0.0f;
+  int k = 0;
+  for (int c = threadIdx.x; c < D; c += 256, ++k) {
+    acc[k] = cnt ? acc[k] / (float)cnt : 0.0f;
+    sq += acc[k] * acc[k];
+  }
+  sq = wave_sum(sq);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sq;
+  __syncthreads();
+  const float nrm = sqrtf((sh[0] + sh[1]) + (sh[2] + sh[3])) + 1e-9f;
+  k = 0;
+  for (int c = threadIdx.x; c < D; c += 256, ++k) out[(size_t)n * D + c] = cnt ? acc[k] / nrm : 0.0f;
+}
+
 #define NI_LAUNCH(H, KERNEL, GRID, STREAM, ...)                                                       \
   do {                                                                                                \
     if ((H) == 256) hipLaunchKernelGGL((KERNEL<1>), GRID, dim3(256), 0, STREAM, __VA_ARGS__);         \
@@ -262,6 +291,13 @@ extern "C" int ufnd_vit_assemble(const float* patch_emb, const float* cls, const
 extern "C" int ufnd_l2norm_frames(const float* e, float* out, int B, int F, int D, void* stream_) {
   UFND_REQUIRE(e && out && B >= 1 && F >= 1 && D >= 1 && D <= 1024, "l2norm_frames: B=%d F=%d D=%d", B, F, D);
   hipLaunchKernelGGL(l2norm_frames_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream_, e, out, F, D);
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}
+
+extern "C" int ufnd_field_mean_l2(const float* parts, const int32_t* valid, float* out, int N, int Mx, int D, void* stream_) {
+  UFND_REQUIRE(parts && valid && out && N >= 1 && Mx >= 1 && D >= 1 && D <= 1024, "field_mean_l2: N=%d M=%d D=%d", N, Mx, D);
+  hipLaunchKernelGGL(field_mean_l2_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream_, parts, valid, out, Mx, D);
   UFND_CHECK_LAUNCH();
   return UFND_OK;
 }

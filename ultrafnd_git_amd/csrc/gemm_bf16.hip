@@ -169,7 +169,32 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
   __builtin_amdgcn_s_barrier();   // everyone is done reading the ring: reuse it for the epilogue
   __builtin_amdgcn_sched_barrier(0);
 
-  // ---- epilogue: 16 rows at a time per wave through a wave-private LDS patch, whole-row stores
+  // ---- epilogue.  Bias and activation are elementwise, so they run on the accumulators where they
+  // lie (straight-line VALU, no LDS dependency); only the layout change for whole-row stores goes
+  // through a wave-private LDS patch, 16 rows at a time, where the fp32 residual is added.
+  if (a.bias) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const float bj = a.bias[n0 + wn * TN + j * 16 + fr];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) acc[i][j] += bj;
+    }
+  }
+  if (a.act == UFND_ACT_GELU) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = gelu_fast_f(acc[i][j][r]);
+  } else if (a.act == UFND_ACT_QUICK_GELU) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = acc[i][j][r] * sigmoid_f(1.702f * acc[i][j][r]);
+  }
   float* cst = reinterpret_cast<float*>(smem) + wave * 16 * CP;
   constexpr int CPR = TN / 8;                    // 8-column chunks per row
   constexpr int CHUNKS = 16 * CPR;               // chunks per 16-row patch
@@ -191,18 +216,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
       const f32x4 v1 = *reinterpret_cast<const f32x4*>(cst + rr * CP + cl + 4);
       if (row >= a.M) continue;
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-      if (a.bias) {
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + col), b1 = *reinterpret_cast<const f32x4*>(a.bias + col + 4);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { v[q] += b0[q]; v[4 + q] += b1[q]; }
-      }
-      if (a.act == UFND_ACT_GELU) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = gelu_f(v[q]);
-      } else if (a.act == UFND_ACT_QUICK_GELU) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = v[q] * sigmoid_f(1.702f * v[q]);
-      }
       if (a.residual) {
         const float* rp = a.residual + (size_t)row * a.ldr + col;
         const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);

@@ -14,6 +14,7 @@ flight -- ~3 ms of MFMA work hides the ~0.1-0.6 ms exchange; the optimizer waits
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -33,7 +34,9 @@ class GradReducer:
         self.grad, self.group = grad, group
         self.world, self.rank = world_info(group)
         self.buckets = buckets or [(0, grad.numel())]
-        self.stream = torch.cuda.Stream(device=grad.device) if grad.is_cuda and self.world > 1 else None
+        # UFND_FORCE_REDUCE=1 runs the collective even at world size 1 (exercises the RCCL path on one GPU)
+        self.force = os.environ.get("UFND_FORCE_REDUCE", "0") == "1" and dist.is_available() and dist.is_initialized()
+        self.stream = torch.cuda.Stream(device=grad.device) if grad.is_cuda and (self.world > 1 or self.force) else None
         self._pending = False
 
     @property
@@ -43,7 +46,7 @@ class GradReducer:
     def start(self) -> None:
         """Begin reducing (asynchronously on a device); gradients must be complete on the
         current stream."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         if self.stream is None:
             for lo, hi in self.buckets:

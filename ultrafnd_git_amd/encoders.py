@@ -203,6 +203,31 @@ class BertTextEncoder(_EncoderBase):
 
     encode_batch = forward
 
+    @torch.no_grad()
+    def encode_fields(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, part_valid: torch.Tensor,
+                      chunk: int = 1024) -> torch.Tensor:
+        """Batched BERTContextEncoder.encode_fields (text_blocks.py:108-128).
+        input_ids / attention_mask (N, M, L): the tokenised parts of N records in the reference's
+        order [title, ocr, up to 10 comments] (M <= 12); part_valid (N, M): 1 where the part exists
+        (the reference skips empty strings).  Every existing part goes through the encoder in one
+        batched pass (the reference runs <= 12 batch-1 forwards per record), then the per-record mean
+        of the part vectors is L2-normalised.  Returns (N, 768); zero rows for records without parts."""
+        self._require_hip()
+        dev = self.device
+        N, Mx, Lq = input_ids.shape
+        valid = part_valid.to(dev, torch.int32).contiguous()
+        ids = input_ids.to(dev, torch.int64).reshape(N * Mx, Lq)
+        mask = attention_mask.to(dev, torch.int32).reshape(N * Mx, Lq)
+        rows = torch.nonzero(valid.reshape(-1), as_tuple=False).flatten()
+        parts = torch.zeros(N * Mx, self.hidden, dtype=torch.float32, device=dev)
+        for s0 in range(0, rows.numel(), chunk):
+            r = rows[s0:s0 + chunk]
+            parts[r] = self.forward(ids[r], mask[r])
+        out = torch.empty(N, self.hidden, dtype=torch.float32, device=dev)
+        L.check(L.lib().ufnd_field_mean_l2(parts.data_ptr(), valid.data_ptr(), out.data_ptr(), N, Mx, self.hidden,
+                                           L.stream_ptr(dev)), "ufnd_field_mean_l2")
+        return out
+
 
 # =============================================================================================
 class ClipVisualEncoder(_EncoderBase):

@@ -142,7 +142,7 @@ class DeviceBatchLoader:
 
 class ForensicTrainer:
     def __init__(self, cfg: TrainConfig, cache: Optional[Dict] = None, text_encoder=None, visual_encoder=None,
-                 group=None):
+                 group=None, temporal_net=None):
         self.cfg = cfg
         os.makedirs(cfg.out_dir, exist_ok=True)
         self.device = torch.device(cfg.device)
@@ -186,6 +186,7 @@ class ForensicTrainer:
                                 seed=cfg.seed + 1000 * self.rank, grad_scale=self.reducer.grad_scale)
         self.scheduler = StepLR(self.optim, step_size=3, gamma=0.7)
         self.text_encoder, self.visual_encoder = text_encoder, visual_encoder
+        self.temporal_net = temporal_net    # optional TemporalSyncNet: temporal = align(text, visual) inside the step
         if cfg.encode_inline and (text_encoder is None or visual_encoder is None):
             raise ValueError("encode_inline=True needs text_encoder= and visual_encoder=")
 
@@ -249,7 +250,10 @@ class ForensicTrainer:
             b["text"].copy_(batch["text_features"])
             b["visual"].copy_(batch["visual_features"])
         b["audio"].copy_(batch["audio_features"])
-        b["temporal"].copy_(batch["temporal_features"])
+        if self.temporal_net is not None and self.cfg.encode_inline and "input_ids" in batch:
+            b["temporal"].copy_(self.temporal_net.align_batch(b["text"], b["visual"]))
+        else:
+            b["temporal"].copy_(batch["temporal_features"])
         b["aux"].copy_(batch["aux"])
         b["label"].copy_(batch["label"])
         ds = self._dataset(split)
@@ -298,7 +302,7 @@ class ForensicTrainer:
                 self._enqueue_backward(b, B)
             torch.cuda.current_stream(self.device).wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self._enqueue_forward(b, B, True, True)
                 self._enqueue_backward(b, B)
             b["graph"] = g
@@ -347,7 +351,8 @@ class ForensicTrainer:
             fn(e)                                   # warm-up: packs weights, allocates buffers
             torch.cuda.current_stream(self.device).synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=torch.cuda.current_stream(self.device)):
+            # thread_local: the RCCL watchdog thread may poll events while this thread captures
+            with torch.cuda.graph(g, stream=torch.cuda.current_stream(self.device), capture_error_mode="thread_local"):
                 fn(e)
             e[which] = g
         e[which].replay()
@@ -409,9 +414,12 @@ class ForensicTrainer:
         for ev in self._feat_ready[slot]:
             main.wait_event(ev)
         self._feat_ready[slot] = None
-        for k_src, k_dst in (("audio_features", "audio"), ("temporal_features", "temporal"), ("aux", "aux"),
-                             ("label", "label"), ("gnn_feat", "gnn")):
+        for k_src, k_dst in (("audio_features", "audio"), ("aux", "aux"), ("label", "label"), ("gnn_feat", "gnn")):
             b[k_dst].copy_(batch[k_src])
+        if self.temporal_net is not None:      # fakesv_dataset.py:176: U = tsync.align(T, V)
+            b["temporal"].copy_(self.temporal_net.align_batch(b["text"], b["visual"]))
+        else:
+            b["temporal"].copy_(batch["temporal_features"])
         self._fwd_bwd(b, B)
         done = torch.cuda.Event()
         done.record(main)
@@ -429,16 +437,18 @@ class ForensicTrainer:
         """(ms of ufnd_gemm_bf16 per step, launches per step): HIP events recorded on the launch
         stream around every GEMM launch of both encoders (an instrumented pass, not the timed one)."""
         events: List[Tuple[torch.cuda.Event, torch.cuda.Event]] = []
+        shapes: List[Tuple[int, int, int]] = []
         originals = []
         for enc in (self.text_encoder, self.visual_encoder):
             orig = enc._gemm
 
-            def timed(*a, _orig=orig, **kw):
+            def timed(A, W, *a, _orig=orig, **kw):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                _orig(*a, **kw)
+                _orig(A, W, *a, **kw)
                 e1.record()
                 events.append((e0, e1))
+                shapes.append((int(A.shape[0]), int(W.shape[0]), int(W.shape[1])))
             originals.append((enc, orig))
             enc._gemm = timed
         try:
@@ -463,6 +473,11 @@ class ForensicTrainer:
         torch.cuda.synchronize(self.device)
         empty = sorted(e0.elapsed_time(e1) for e0, e1 in pairs)[len(pairs) // 2]
         total = sum(max(0.0, e0.elapsed_time(e1) - empty) for e0, e1 in events)
+        self.last_gemm_by_shape = {}
+        for (e0, e1), shp in zip(events, shapes):
+            d = self.last_gemm_by_shape.setdefault("x".join(map(str, shp)), [0, 0.0])
+            d[0] += 1
+            d[1] += max(0.0, e0.elapsed_time(e1) - empty)
         return total / steps, len(events) // steps
 
     def _forward_batch(self, batch, split: str) -> Dict[str, torch.Tensor]:
