@@ -27,6 +27,7 @@ struct GemmArgs {
   float* out_f32;
   int M, N, K, lda, ldw, ldr, ldo, ldf, act;
   int m_tiles, n_tiles;
+  int ksplit;            // > 1: block (tile, s) multiplies K-slice s and writes raw fp32 partials to slab s
 };
 
 __device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst) {
@@ -71,12 +72,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
   // XCD-aware bijective remap of the block id
-  const int nblk = a.m_tiles * a.n_tiles;
+  const int nblk = a.m_tiles * a.n_tiles * a.ksplit;
   int bid;
   {
     const int q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
+  const int ks = bid % a.ksplit;
+  bid /= a.ksplit;
   const int m0 = (bid / a.n_tiles) * BM, n0 = (bid % a.n_tiles) * BN;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int wm = wave / WN, wn = wave % WN, fr = lane & 15, g = lane >> 4;
@@ -87,10 +90,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = a.K / BK;
+  const int nk = a.K / BK / a.ksplit;         // K-steps of this block's slice
+  const int kbase = ks * nk * BK;
   auto issue = [&](int t) {
     char* buf = smem + (t % ST) * STAGE;
-    const int k0 = t * BK;
+    const int k0 = kbase + t * BK;
 #pragma unroll
     for (int ii = 0; ii < PW; ++ii) {
       const int p = wave + NW * ii;                  // piece id: rows 8p..8p+7 of [A tile ; W tile]
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         for (int q = 0; q < 4; ++q) { v[q] += r0[q]; v[4 + q] += r1[q]; }
       }
       if (a.out_f32) {
-        float* op = a.out_f32 + (size_t)row * a.ldf + col;
+        float* op = a.out_f32 + (size_t)ks * a.M * a.ldf + (size_t)row * a.ldf + col;
         *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
         *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
       }
@@ -285,7 +289,7 @@ static int launch_cfg(int cfg, int abl, int sch, GemmArgs& a, hipStream_t stream
   const TileCfg& t = kTiles[cfg];
   a.m_tiles = ufnd_cdiv(a.M, t.bm);
   a.n_tiles = a.N / t.bn;
-  const dim3 grid(a.m_tiles * a.n_tiles), block(t.threads);
+  const dim3 grid(a.m_tiles * a.n_tiles * a.ksplit), block(t.threads);
 #define GO(BM_, BN_, WM_, WN_, ST_)                                                                               \
   do {                                                                                                              \
     if (abl == 0 && sch == 1) hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, ST_, 0, 1>), grid, block, 0, stream, a); \
@@ -353,7 +357,7 @@ extern "C" int ufnd_gemm_bf16_ex(const void* A, const void* W, const float* bias
   UFND_REQUIRE(!out_bf16 || (ldo % 8 == 0 && ldo >= N && ufnd_aligned(out_bf16, 16)), "gemm_bf16: out_bf16 alignment");
   UFND_REQUIRE(!bias || ufnd_aligned(bias, 4), "gemm_bf16: bias alignment");
   UFND_REQUIRE(act >= 0 && act <= 2, "gemm_bf16: act=%d", act);
-  GemmArgs a{(const __bf16*)A, (const __bf16*)W, bias, residual, (__bf16*)out_bf16, out_f32, M, N, K, lda, ldw, ldr, ldo, ldf, act, 0, 0};
+  GemmArgs a{(const __bf16*)A, (const __bf16*)W, bias, residual, (__bf16*)out_bf16, out_f32, M, N, K, lda, ldw, ldr, ldo, ldf, act, 0, 0, 1};
   // tile_cfg >= 0: explicit tile; +100 / +200 select the timing-only ablations (no MFMA / no in-loop DMA)
   // automatic choice uses the explicit software-pipelined schedule (5-12 % faster on every shape swept)
   int abl = 0, sch = tile_cfg < 0 ? 1 : 0, cfg = tile_cfg < 0 ? auto_cfg(M, N, K) : tile_cfg;
@@ -362,6 +366,23 @@ extern "C" int ufnd_gemm_bf16_ex(const void* A, const void* W, const float* bias
   UFND_REQUIRE(cfg < kNumTiles, "gemm_bf16: unknown tile config %d", cfg);
   UFND_REQUIRE(N % kTiles[cfg].bn == 0, "gemm_bf16: tile config %d needs N %% %d == 0", cfg, kTiles[cfg].bn);
   int rc = launch_cfg(cfg, abl, sch, a, (hipStream_t)stream_);
+  if (rc != UFND_OK) return rc;
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}
+
+extern "C" int ufnd_gemm_bf16_splitk(const void* A, const void* W, float* slabs, int M, int N, int K, int lda, int ldw, int ksplit,
+                                     int tile_cfg, void* stream_) {
+  UFND_REQUIRE(A && W && slabs, "gemm_bf16_splitk: null operand");
+  UFND_REQUIRE(ksplit >= 1 && ksplit <= 8 && K % (64 * ksplit) == 0, "gemm_bf16_splitk: K=%d not divisible into %d slices of 64-steps", K, ksplit);
+  UFND_REQUIRE(M >= 1 && N >= 64 && N % 64 == 0, "gemm_bf16_splitk: M=%d N=%d", M, N);
+  UFND_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K && ufnd_aligned(A, 16) && ufnd_aligned(W, 16) && ufnd_aligned(slabs, 16),
+               "gemm_bf16_splitk: alignment");
+  GemmArgs a{(const __bf16*)A, (const __bf16*)W, nullptr, nullptr, nullptr, slabs, M, N, K, lda, ldw, 0, 0, N, 0, 0, 0, ksplit};
+  int cfg = tile_cfg < 0 ? 17 : tile_cfg;     // 128x192, 8 waves
+  if (N % kTiles[cfg < kNumTiles ? cfg : 0].bn != 0) cfg = 1;
+  UFND_REQUIRE(cfg < kNumTiles && N % kTiles[cfg].bn == 0, "gemm_bf16_splitk: tile config %d does not divide N=%d", cfg, N);
+  int rc = launch_cfg(cfg, 0, 1, a, (hipStream_t)stream_);
   if (rc != UFND_OK) return rc;
   UFND_CHECK_LAUNCH();
   return UFND_OK;

@@ -80,9 +80,13 @@ class _EncoderBase(nn.Module):
             raise L.UltrafndHipError(f"{type(self).__name__} runs on a HIP device only: call .to('cuda') (no CPU fallback)")
 
     # ---- thin wrappers over the C ABI
-    def _gemm(self, A, W, bias, out_bf16=None, out_f32=None, residual=None, act=ACT_NONE, M=None):
+    def _gemm(self, A, W, bias, out_bf16=None, out_f32=None, residual=None, act=ACT_NONE, M=None, slabs=None):
         M = A.shape[0] if M is None else M
         N, K = W.shape
+        if slabs is not None:       # split-K: raw partials per K-slice, reduced by ufnd_layernorm_sum
+            L.check(L.lib().ufnd_gemm_bf16_splitk(A.data_ptr(), W.data_ptr(), slabs.data_ptr(), M, N, K, A.stride(0), W.stride(0),
+                                                  slabs.shape[0], -1, L.stream_ptr(A.device)), "ufnd_gemm_bf16_splitk")
+            return
         L.check(L.lib().ufnd_gemm_bf16(A.data_ptr(), W.data_ptr(), L.ptr(bias), L.ptr(residual), L.ptr(out_bf16),
                                        L.ptr(out_f32), M, N, K, A.stride(0), W.stride(0),
                                        residual.stride(0) if residual is not None else 0,
@@ -108,6 +112,8 @@ class BertTextEncoder(_EncoderBase):
             raise ValueError("head_dim must be 64 (hidden == heads * 64)")
         self.layers, self.hidden, self.heads, self.inter, self.vocab, self.eps = layers, hidden, heads, intermediate, vocab_size, eps
         self.max_position = max_position
+        # output.dense as a 2-way split-K GEMM when the token count gives a full wave of 128x192 tiles
+        self.ffn2_split = 2 if (intermediate % 128 == 0 and hidden % 192 == 0) else 1
         w = self._w
         g = torch.Generator().manual_seed(0)
 
@@ -156,6 +162,7 @@ class BertTextEncoder(_EncoderBase):
             dev, M, H = self.device, B * Lq, self.hidden
             bf, f32 = dict(dtype=torch.bfloat16, device=dev), dict(dtype=torch.float32, device=dev)
             self._bufs[key] = {"xb": torch.empty(M, H, **bf), "xf": torch.empty(M, H, **f32), "y": torch.empty(M, H, **f32),
+                               "slabs": torch.empty(self.ffn2_split, M, H, **f32),
                                "x1b": torch.empty(M, H, **bf), "x1f": torch.empty(M, H, **f32),
                                "qkv": torch.empty(M, 3 * H, **bf), "ctx": torch.empty(M, H, **bf),
                                "h": torch.empty(M, self.inter, **bf), "feat": torch.empty(B, H, **f32)}
@@ -187,8 +194,15 @@ class BertTextEncoder(_EncoderBase):
             self._gemm(b["ctx"], ly["wo"], ly["bo"], out_f32=b["y"], residual=b["xf"])
             self._ln(b["y"], H, ly["g1"], ly["b1"], b["x1b"], b["x1f"], M, H, self.eps)
             self._gemm(b["x1b"], ly["w1"], ly["bi"], out_bf16=b["h"], act=ACT_GELU)
-            self._gemm(b["h"], ly["w2"], ly["b2"], out_f32=b["y"], residual=b["x1f"])
-            self._ln(b["y"], H, ly["g2"], ly["b2n"], b["xb"], b["xf"], M, H, self.eps)
+            if self.ffn2_split > 1:
+                # output.dense (K = 3072): split-K partial slabs, reduced + bias + residual inside the LayerNorm
+                self._gemm(b["h"], ly["w2"], None, slabs=b["slabs"])
+                L.check(L.lib().ufnd_layernorm_sum(b["slabs"].data_ptr(), self.ffn2_split, ly["b2"].data_ptr(), b["x1f"].data_ptr(), H,
+                                               ly["g2"].data_ptr(), ly["b2n"].data_ptr(), b["xb"].data_ptr(), b["xf"].data_ptr(), None,
+                                               M, H, self.eps, L.stream_ptr(dev)), "ufnd_layernorm_sum")
+            else:
+                self._gemm(b["h"], ly["w2"], ly["b2"], out_f32=b["y"], residual=b["x1f"])
+                self._ln(b["y"], H, ly["g2"], ly["b2n"], b["xb"], b["xf"], M, H, self.eps)
         return b["xf"].view(B, Lq, H)
 
     @torch.no_grad()
