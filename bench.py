@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1]: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--head-only", action="store_true",
+                    help="secondary measurement: the reference's actual training mode (cached features, no encoders in the step)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -121,6 +123,26 @@ def main():
 
     B = args.batch
     torch.manual_seed(42)
+    if args.head_only:
+        cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir="/tmp/ufnd_bench", batch_size=B, device=str(dev),
+                          use_graph=not args.no_graph, seed=42)
+        tr = ForensicTrainer(cfg, cache=synthetic_cache(max(64, 8 * B), seed=1))
+        tr.fusion.train(); tr.clf.train()
+        bl = [tr.train_loader.dataset.gather(torch.arange(B, device=dev) % len(tr.train_loader.dataset)) for _ in range(2)]
+        for i in range(args.warmup):
+            tr.train_step(bl[i % 2])
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            tr.train_step(bl[i % 2])
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        P = tr.arena.n_grad
+        print(json.dumps({"metric": "head-only train-step samples/sec (cached features)", "value": round(B * args.steps / dt, 1),
+                          "unit": "samples/s", "ms_per_step": round(dt / args.steps * 1e3, 4), "batch": B, "n_gpus": 1,
+                          "algorithmic_MB_per_step": round(11 * 4 * P / 1e6, 1),
+                          "hbm_GBps_algorithmic": round(11 * 4 * P / (dt / args.steps) / 1e9, 1)}))
+        return
     tenc = BertTextEncoder().to(dev)            # BERT-base geometry, random init (no checkpoints offline)
     venc = ClipVisualEncoder().to(dev)          # CLIP ViT-B/32 geometry, random init
     cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir="/tmp/ufnd_bench", batch_size=B, device=str(dev),

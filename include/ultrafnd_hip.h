@@ -127,14 +127,21 @@ int ufnd_fusion_forward(const ufnd_dims* d, const ufnd_fusion_params* p, const f
                         float* workspace, float* fused, int ld_fused, float* logits, float* forensic,
                         const ufnd_step_state* state, void* stream);
 
-/* autograd backward of the above (what loss.backward() runs, forensic_trainer.py:291).
+/* The two backward entry points take an optional `side_stream` (NULL = everything on `stream`): the
+ * dX chain -- the critical path -- stays on `stream`, every dW / parameter-gradient kernel goes to
+ * `side_stream`, forked with events as soon as its inputs exist.  `join` != 0 makes `stream` wait for
+ * the side work before the call returns control of the stream (pass 0 to keep the overlap going into
+ * the next call and join there).  Event record/wait pairs are capturable into a hipGraph.
+ *
+ * autograd backward of the above (what loss.backward() runs, forensic_trainer.py:291).
  *   d_fused (B,hidden) stride ld_dfused; d_logits (B,2) or NULL.  Writes EVERY gradient in
  *   `g` that can receive one (cls_w/cls_b only when d_logits != NULL; overwritten, not
  *   accumulated).  Inputs get no gradient (they are data). */
 int ufnd_fusion_backward(const ufnd_dims* d, const ufnd_fusion_params* p, const ufnd_fusion_params* g,
                          const float* text, const float* audio, const float* visual, const float* temporal,
                          const float* gnn, int B, int train, float* workspace, const float* d_fused,
-                         int ld_dfused, const float* d_logits, const ufnd_step_state* state, void* stream);
+                         int ld_dfused, const float* d_logits, const ufnd_step_state* state, void* stream,
+                         void* side_stream, int join);
 
 /* ------------------------------------------------------------------------------------
  * DeepTruthClassifier.forward                   src/models/fusion/deep_truth_classifier.py:148-171
@@ -152,7 +159,7 @@ int ufnd_classifier_forward(const ufnd_dims* d, const ufnd_clf_params* p, const 
  * ld_dfused is written. */
 int ufnd_classifier_backward(const ufnd_dims* d, const ufnd_clf_params* p, const ufnd_clf_params* g, int B,
                              int train, float* workspace, const float* d_logits, float* d_fused, int ld_dfused,
-                             const ufnd_step_state* state, void* stream);
+                             const ufnd_step_state* state, void* stream, void* side_stream, int join);
 
 /* F.cross_entropy(logits, y), mean reduction, + its gradient (forensic_trainer.py:287).
  * labels int64 (B).  loss_rows (B) or NULL; d_logits (B,2) = (softmax - onehot)/B or NULL.

@@ -66,10 +66,10 @@ def _declare(lib: C.CDLL) -> None:
     lib.ufnd_clf_input_panel.argtypes = [C.POINTER(Dims), P, I, C.POINTER(I)]
     lib.ufnd_fusion_forward.argtypes = [C.POINTER(Dims), C.POINTER(FusionParams), P, P, P, P, P, I, I, P, P, I, P, P, P, P]
     lib.ufnd_fusion_backward.argtypes = [C.POINTER(Dims), C.POINTER(FusionParams), C.POINTER(FusionParams),
-                                         P, P, P, P, P, I, I, P, P, I, P, P, P]
+                                         P, P, P, P, P, I, I, P, P, I, P, P, P, P, I]
     lib.ufnd_classifier_forward.argtypes = [C.POINTER(Dims), C.POINTER(ClfParams), P, I, P, I, I, P, P, P, P, P]
     lib.ufnd_classifier_backward.argtypes = [C.POINTER(Dims), C.POINTER(ClfParams), C.POINTER(ClfParams), I, I, P, P, P,
-                                             I, P, P]
+                                             I, P, P, P, I]
     lib.ufnd_softmax_ce.argtypes = [P, P, I, P, P, P, P]
     lib.ufnd_grad_norm.argtypes = [P, S, P, P, P]
     lib.ufnd_adamw_step.argtypes = [P, P, P, P, S, P, P]

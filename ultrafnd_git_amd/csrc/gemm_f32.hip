@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void nn_kernel(const NnArgs args) {
   const float* wcol = P.W + (kok ? kcol : 0);
 
   // batches of U chunks (8 weight rows each): all 5U loads of a batch in flight before its MFMAs
-  constexpr int U = (VEC == 4) ? 4 : 6;
+  constexpr int U = (VEC == 4) ? 4 : (VEC == 2 ? 6 : 8);
   for (int n = n0; n < n1; n += 8 * U) {
     float a[U][4], b[U][4][VEC];
 #pragma unroll
@@ -238,9 +238,11 @@ __global__ __launch_bounds__(256) void nn_kernel(const NnArgs args) {
           if constexpr (VEC == 4) {
             const f32x4 t = *reinterpret_cast<const f32x4*>(src);
             b[u][e][0] = t[0]; b[u][e][1] = t[1]; b[u][e][2] = t[2]; b[u][e][3] = t[3];
-          } else {
+          } else if constexpr (VEC == 2) {
             const f32x2 t = *reinterpret_cast<const f32x2*>(src);
             b[u][e][0] = t[0]; b[u][e][1] = t[1];
+          } else {
+            b[u][e][0] = *src;
           }
         } else {
 #pragma unroll
@@ -450,15 +452,25 @@ int launch_nn(const NnProb* probs, int nprob, const ufnd_step_state* st, hipStre
     if (!(p.K % 4 == 0 && p.ldw % 4 == 0 && ufnd_aligned(p.W, 16))) vec4 = false;
     a.p[i] = p;
   }
-  const int VEC = vec4 ? 4 : 2;
+  int VEC = vec4 ? 4 : 2;
+  auto count = [&](int vec) {
+    int t = 0;
+    for (int i = 0; i < nprob; ++i) t += ufnd_cdiv(a.p[i].K, 32 * vec) * ufnd_cdiv(a.p[i].M, 32) * a.p[i].nsplit;
+    return t;
+  };
+  // A wave's MFMA chain is (contraction / 32) * VEC long at 64 cycles each: when a launch has only a
+  // handful of blocks, narrow the strips (more blocks, shorter chains) -- the work is latency-, not
+  // bandwidth-bound at that size.
+  if (count(VEC) < 64) VEC = 1;
   int total = 0;
   for (int i = 0; i < nprob; ++i) {
     a.begin[i] = total;
     total += ufnd_cdiv(a.p[i].K, 32 * VEC) * ufnd_cdiv(a.p[i].M, 32) * a.p[i].nsplit;
   }
   a.begin[nprob] = total;
-  if (vec4) hipLaunchKernelGGL((nn_kernel<4>), dim3(total), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL((nn_kernel<2>), dim3(total), dim3(256), 0, stream, a);
+  if (VEC == 4) hipLaunchKernelGGL((nn_kernel<4>), dim3(total), dim3(256), 0, stream, a);
+  else if (VEC == 2) hipLaunchKernelGGL((nn_kernel<2>), dim3(total), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((nn_kernel<1>), dim3(total), dim3(256), 0, stream, a);
   UFND_CHECK_LAUNCH();
   return UFND_OK;
 }

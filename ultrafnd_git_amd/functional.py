@@ -74,7 +74,7 @@ class FusionFunction(torch.autograd.Function):
         L.check(L.lib().ufnd_fusion_backward(C.byref(d), C.byref(module.param_table()), C.byref(gt), text.data_ptr(),
                                              audio.data_ptr(), visual.data_ptr(), temporal.data_ptr(), gnn.data_ptr(),
                                              ctx.B, int(ctx.train), module.workspace(ctx.B, True).data_ptr(), L.ptr(df),
-                                             H, L.ptr(dl), module.rng().ptr, L.stream_ptr(dev)), "ufnd_fusion_backward")
+                                             H, L.ptr(dl), module.rng().ptr, L.stream_ptr(dev), None, 1), "ufnd_fusion_backward")
         _bind_grads(module)
         if dl is not None:
             module.classifier.weight.grad = module._cls_grad[:2 * H].view(2, H).clone()
@@ -133,7 +133,7 @@ class ClassifierFunction(torch.autograd.Function):
         L.check(L.lib().ufnd_classifier_backward(C.byref(d), C.byref(module.param_table()), C.byref(module.grad_table()),
                                                  ctx.B, int(ctx.train), module.workspace(ctx.B, True).data_ptr(),
                                                  dl.data_ptr(), d_fused.data_ptr(), H, module.rng().ptr,
-                                                 L.stream_ptr(dev)), "ufnd_classifier_backward")
+                                                 L.stream_ptr(dev), None, 1), "ufnd_classifier_backward")
         _bind_grads(module)
         return (None, None, None, d_fused, None) + (None,) * nparams
 

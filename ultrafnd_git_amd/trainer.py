@@ -196,6 +196,9 @@ class ForensicTrainer:
         self._step_bufs: Dict[Tuple[int, bool, int], dict] = {}
         self._enc_bufs: Dict[Tuple[int, int, int], dict] = {}
         self._enc_streams = None
+        self._dw_stream: Optional[torch.cuda.Stream] = None
+        # the head's fwd/bwd as a graph (default with use_graph) or eager with the dW side stream
+        self._head_graph = cfg.use_graph and os.environ.get("UFND_HEAD_GRAPH", "1") != "0"
         self._slot = 0
         self._feat_ready = [None, None]
         self._slot_free = [None, None]
@@ -280,17 +283,25 @@ class ForensicTrainer:
     def _enqueue_backward(self, b: dict, B: int) -> None:
         lib, s, st = L.lib(), L.stream_ptr(self.device), self.optim.state.ptr
         d = b["dims"]
+        # Eager launches: dW / parameter-gradient kernels run beside the dX chain on a second stream (joined
+        # at the end).  Inside a captured hipGraph the fork/join costs more than it hides (ROCm 7 replays
+        # multi-branch graphs almost serially -- measured), so the graph keeps one stream.
+        side = None
+        if not self._head_graph:
+            if self._dw_stream is None:
+                self._dw_stream = torch.cuda.Stream(device=self.device)
+            side = self._dw_stream.cuda_stream
         L.check(lib.ufnd_classifier_backward(C.byref(d), C.byref(self.clf.param_table()), C.byref(self.clf.grad_table()), B, 1,
                                              b["cws"].data_ptr(), b["dlogits"].data_ptr(), b["dfused"].data_ptr(),
-                                             self.fusion.hidden, st, s), "ufnd_classifier_backward")
+                                             self.fusion.hidden, st, s, side, 0), "ufnd_classifier_backward")
         L.check(lib.ufnd_fusion_backward(C.byref(d), C.byref(self.fusion.param_table()), C.byref(self.fusion.grad_table()),
                                          b["text"].data_ptr(), b["audio"].data_ptr(), b["visual"].data_ptr(),
                                          b["temporal"].data_ptr(), b["gnn"].data_ptr(), B, 1, b["fws"].data_ptr(),
-                                         b["dfused"].data_ptr(), self.fusion.hidden, None, st, s), "ufnd_fusion_backward")
+                                         b["dfused"].data_ptr(), self.fusion.hidden, None, st, s, side, 1), "ufnd_fusion_backward")
 
     def _fwd_bwd(self, b: dict, B: int) -> None:
         """fusion fwd -> clf fwd -> CE -> clf bwd -> fusion bwd, eager or replayed from a hipGraph."""
-        if not self.cfg.use_graph:
+        if not self._head_graph:
             self._enqueue_forward(b, B, True, True)
             self._enqueue_backward(b, B)
             return
