@@ -292,6 +292,28 @@ def tier_b():
     np.savez_compressed(HERE / "tier_b.npz", **store)
 
 
+def init_parity():
+    """Per-tensor checksums of the reference modules' INITIAL weights under torch.manual_seed(123): the
+    mirror constructs its parameters in the same order, so the same seed must give the same weights."""
+    sys.modules["transformers"] = None
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, str(REF))
+    os.chdir(REF)
+    from src.models.fusion.cross_modal_transformer import CrossModalTransformer
+    from src.models.fusion.deep_truth_classifier import DeepTruthClassifier
+    from src.training.forensic_trainer import TrainConfig
+    import dataclasses
+    torch.manual_seed(123)
+    fusion = CrossModalTransformer("configs/model_configs/fusion.yaml")
+    clf = DeepTruthClassifier("configs/model_configs/classifier.yaml")
+    out = {"fusion": {k: [list(v.shape), float(v.double().sum()), float(v.double().abs().sum())] for k, v in fusion.state_dict().items()},
+           "clf": {k: [list(v.shape), float(v.double().sum()), float(v.double().abs().sum())] for k, v in clf.state_dict().items()},
+           "train_config_fields": [[f.name, repr(f.default) if f.default is not dataclasses.MISSING else None]
+                                   for f in dataclasses.fields(TrainConfig)]}
+    (HERE / "init_parity.json").write_text(json.dumps(out, indent=0))
+    print("init_parity:", len(out["fusion"]), "+", len(out["clf"]), "tensors,", len(out["train_config_fields"]), "TrainConfig fields")
+
+
 def temporal():
     """TemporalSyncNet.align (src/core_blocks/temporal_blocks.py:102-140) with seeded weights."""
     sys.dont_write_bytecode = True
@@ -321,7 +343,7 @@ def temporal():
 if __name__ == "__main__":
     part = sys.argv[1] if len(sys.argv) > 1 else "all"
     if part == "all":
-        for p in ("tier_a", "metrics", "tier_b", "temporal"):
+        for p in ("tier_a", "metrics", "tier_b", "temporal", "init_parity"):
             subprocess.check_call([sys.executable, str(Path(__file__).resolve()), p], cwd=str(REPO))
     else:
-        {"tier_a": tier_a, "metrics": metrics, "tier_b": tier_b, "temporal": temporal}[part]()
+        {"tier_a": tier_a, "metrics": metrics, "tier_b": tier_b, "temporal": temporal, "init_parity": init_parity}[part]()

@@ -1,0 +1,158 @@
+"""CPU: host-side logic of the drop-in layer -- module structure and initialisation parity with the
+reference, arena layout, config loading, scheduler, loaders, loud failure without a HIP device."""
+import dataclasses
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import GOLDEN
+
+
+@pytest.fixture(scope="module")
+def parity():
+    return json.loads((GOLDEN / "init_parity.json").read_text())
+
+
+def test_same_seed_gives_the_reference_initial_weights(parity):
+    """state_dict keys, order, shapes AND values of freshly constructed modules equal the reference's under
+    the same torch seed (parameters are created in the reference's order; tests/golden/init_parity.json)."""
+    from ultrafnd_git_amd.classifier import DeepTruthClassifier
+    from ultrafnd_git_amd.fusion import CrossModalTransformer
+    torch.manual_seed(123)
+    fusion, clf = CrossModalTransformer(), DeepTruthClassifier()
+    for mod, ref in ((fusion, parity["fusion"]), (clf, parity["clf"])):
+        sd = mod.state_dict()
+        assert list(sd.keys()) == list(ref.keys())
+        for k, (shape, s, a) in ref.items():
+            assert list(sd[k].shape) == shape, k
+            assert abs(float(sd[k].double().sum()) - s) <= 1e-9 * max(1.0, a), k
+            assert abs(float(sd[k].double().abs().sum()) - a) <= 1e-9 * max(1.0, a), k
+    assert sum(p.numel() for p in fusion.parameters()) == 12_732_421
+    assert sum(p.numel() for p in clf.parameters()) == 539_873
+
+
+def test_train_config_mirrors_the_reference_dataclass(parity):
+    from ultrafnd_git_amd.trainer import TrainConfig
+    mine = [(f.name, repr(f.default) if f.default is not dataclasses.MISSING else None) for f in dataclasses.fields(TrainConfig)]
+    ref = [tuple(x) for x in parity["train_config_fields"]]
+    assert mine[:len(ref)] == ref                 # same fields, order and defaults; additions only at the end
+    assert [n for n, _ in mine[len(ref):]] == ["device", "use_graph", "encode_inline"]
+
+
+def test_arena_layout_keeps_stacked_groups_contiguous_and_aligned():
+    from ultrafnd_git_amd.arena import rehome
+    from ultrafnd_git_amd.classifier import DeepTruthClassifier
+    from ultrafnd_git_amd.fusion import _QKV_ORDER, CrossModalTransformer
+    fusion, clf = CrossModalTransformer(), DeepTruthClassifier()
+    arena = rehome([clf, fusion], ["clf.", "fusion."])
+    H = fusion.hidden
+    off = arena.offsets
+    base = off["fusion.attn_tv.q.weight"][0]
+    for i, (blk, p) in enumerate(_QKV_ORDER):
+        assert off[f"fusion.{blk}.{p}.weight"][0] == base + i * H * H
+        assert off[f"fusion.{blk}.{p}.bias"][0] == off["fusion.attn_tv.q.bias"][0] + i * H
+    g0 = off["clf.node.trees.0.gates.0"][0]
+    for t in range(6):
+        for k in range(4):
+            assert off[f"clf.node.trees.{t}.gates.{k}"][0] == g0 + (t * 4 + k) * H
+            assert off[f"clf.node.trees.{t}.thresh.{k}"][0] == off["clf.node.trees.0.thresh.0"][0] + t * 4 + k
+    for key in ("fusion.fuse_mlp.0.weight", "fusion.text_proj.weight", "clf.pre.0.weight", "fusion.attn_tv.q.weight"):
+        assert off[key][0] % 64 == 0
+    # no-grad tensors sit behind the gradient range; the range holds exactly the 12,745,949 trainable scalars
+    nograd = [k for k in off if not arena.has_grad(k)]
+    assert sorted(nograd) == sorted(["clf.temperature"] + [f"clf.node.trees.{t}.tau" for t in range(6)] +
+                                    [f"fusion.semantic.{n}.0.{w}" for n in ("text_proj", "vision_proj") for w in ("weight", "bias")] +
+                                    ["fusion.classifier.weight", "fusion.classifier.bias"])
+    n_train = sum(int(np.prod(off[k][1])) if off[k][1] else 1 for k in off if arena.has_grad(k))
+    assert n_train == 12_745_949 and arena.n_grad % 64 == 0 and arena.n_grad >= n_train
+    # parameters really are views of the arena and load_state_dict writes through
+    p = dict(fusion.named_parameters())["fuse_mlp.3.bias"]
+    assert p.data_ptr() == arena.view("fusion.fuse_mlp.3.bias").data_ptr()
+    sd = fusion.state_dict()
+    sd["fuse_mlp.3.bias"] = torch.full_like(sd["fuse_mlp.3.bias"], 0.25)
+    fusion.load_state_dict(sd)
+    assert float(arena.view("fusion.fuse_mlp.3.bias").mean()) == 0.25
+
+
+def test_config_manager_semantics(tmp_path):
+    """src/utils/config_utils.py:34-71: missing file -> {}, non-dict YAML -> {}, defaults merged, cached."""
+    from ultrafnd_git_amd.config_utils import ConfigManager, load_yaml
+    cm = ConfigManager()
+    assert cm.load_config(str(tmp_path / "nope.yaml")) == {}
+    assert cm.load_config(str(tmp_path / "nope.yaml"), defaults={"a": 1}) == {"a": 1}
+    (tmp_path / "l.yaml").write_text("- 1\n- 2\n")
+    assert cm.load_config(str(tmp_path / "l.yaml")) == {}
+    (tmp_path / "ok.yaml").write_text("hidden_dim: 256\ndropout: 0.2\n")
+    assert cm.load_config(str(tmp_path / "ok.yaml"), defaults={"hidden_dim": 1, "x": 2}) == {"hidden_dim": 256, "x": 2, "dropout": 0.2}
+    (tmp_path / "ok.yaml").write_text("hidden_dim: 999\n")
+    assert cm.load_config(str(tmp_path / "ok.yaml"))["hidden_dim"] == 256           # cached per instance
+    assert load_yaml("configs/model_configs/fusion.yaml")["hidden_dim"] == 512      # resolved against the repo root
+    assert load_yaml("configs/model_configs/classifier.yaml")["node_trees"] == 6
+
+
+def test_code_defaults_apply_when_yaml_is_missing():
+    """cross_modal_transformer.py:87 / deep_truth_classifier.py:107: dropout 0.3 if the YAML is absent (0.1 with it)."""
+    from ultrafnd_git_amd.classifier import DeepTruthClassifier
+    from ultrafnd_git_amd.fusion import CrossModalTransformer
+    assert CrossModalTransformer("does/not/exist.yaml").dropout == 0.3
+    assert CrossModalTransformer().dropout == 0.1
+    assert DeepTruthClassifier("does/not/exist.yaml").dropout == 0.3 and DeepTruthClassifier().dropout == 0.1
+
+
+def test_everything_refuses_to_run_without_a_hip_device(tmp_path):
+    from ultrafnd_git_amd._lib import UltrafndHipError
+    from ultrafnd_git_amd.classifier import DeepTruthClassifier
+    from ultrafnd_git_amd.encoders import BertTextEncoder, ClipVisualEncoder
+    from ultrafnd_git_amd.temporal import TemporalSyncNet
+    from ultrafnd_git_amd.trainer import ForensicTrainer, TrainConfig, synthetic_cache
+    with pytest.raises(UltrafndHipError):
+        DeepTruthClassifier()(torch.zeros(2, 512), torch.zeros(2, 2))
+    with pytest.raises(UltrafndHipError):
+        BertTextEncoder(layers=1, vocab_size=50)(torch.zeros(1, 8, dtype=torch.long), torch.ones(1, 8, dtype=torch.long))
+    with pytest.raises(UltrafndHipError):
+        ClipVisualEncoder(layers=1)(torch.zeros(1, 3, 224, 224))
+    with pytest.raises(UltrafndHipError):
+        TemporalSyncNet().align(np.zeros(768, np.float32), np.zeros(512, np.float32))
+    with pytest.raises(UltrafndHipError):
+        ForensicTrainer(TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir=str(tmp_path), device="cpu"), cache=synthetic_cache(8))
+
+
+def test_cached_dataset_and_loader_on_host_tensors():
+    """CachedTensorDataset item schema (forensic_trainer.py:73-83) and DataLoader-equivalent batching."""
+    from ultrafnd_git_amd.trainer import CachedTensorDataset, DeviceBatchLoader, synthetic_cache
+    cache = synthetic_cache(23, seed=4)
+    tr_idx = cache["split"][0]
+    ds = CachedTensorDataset(cache, tr_idx)
+    assert len(ds) == len(tr_idx) == 16
+    item = ds[3]
+    assert set(item) == {"text_features", "audio_features", "visual_features", "temporal_features", "aux", "label", "index"}
+    assert item["index"] == 3 and item["text_features"].shape == (768,) and item["label"].dtype == torch.int64
+    assert np.allclose(item["text_features"].numpy(), cache["text"][tr_idx[3]])
+    sizes = [b["label"].shape[0] for b in DeviceBatchLoader(ds, 5, shuffle=False)]
+    assert sizes == [5, 5, 5, 1]                                   # drop_last=False
+    ld = DeviceBatchLoader(ds, 16, shuffle=True, seed=1)
+    e1 = next(iter(ld))["index"].tolist()
+    e2 = next(iter(ld))["index"].tolist()
+    assert sorted(e1) == list(range(16)) and e1 != e2               # reshuffled every epoch
+    b = next(iter(DeviceBatchLoader(ds, 4, shuffle=False)))
+    assert torch.equal(b["index"], torch.arange(4)) and b["aux"].shape == (4, 2)
+
+
+def test_step_lr_matches_torch():
+    """StepLR(step_size=3, gamma=0.7) (forensic_trainer.py:177) vs torch's own scheduler."""
+    from ultrafnd_git_amd.optim import StepLR
+
+    class FakeOpt:
+        param_groups = [{"lr": 2e-4, "initial_lr": 2e-4}]
+
+        def set_lr(self, lr):
+            self.param_groups[0]["lr"] = lr
+    mine = StepLR(FakeOpt(), 3, 0.7)
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=2e-4)
+    ref = torch.optim.lr_scheduler.StepLR(opt, step_size=3, gamma=0.7)
+    for _ in range(10):
+        opt.step(); ref.step(); mine.step()
+        assert abs(mine.get_last_lr()[0] - ref.get_last_lr()[0]) < 1e-15
