@@ -206,11 +206,18 @@ int ufnd_gemm_bf16(const void* A, const void* W, const float* bias, const float*
                    void* stream);
 
 /* Same, with an explicit tile configuration (tuning / benchmarking): tile_cfg < 0 = automatic;
- * 0: 128x128 3-stage, 1: 128x64 3-stage, 2: 256x128 3-stage (8 waves), 3: 128x128 2-stage,
- * 4: 128x64 4-stage, 5: 256x64 3-stage (8 waves).  N must be a multiple of the tile width. */
+ * otherwise an index into the tile table of csrc/gemm_bf16.hip (UFND_GEMM_TILES: block tile, wave
+ * grid, LDS ring slots of the A and W operands).  N must be a multiple of the tile width. */
 int ufnd_gemm_bf16_ex(const void* A, const void* W, const float* bias, const float* residual, void* out_bf16,
                       float* out_f32, int M, int N, int K, int lda, int ldw, int ldr, int ldo, int ldf, int act,
                       int tile_cfg, void* stream);
+
+/* Diagnostics: one launch of tile `tile_cfg` (plain bf16 output, no epilogue extras) built with
+ * in-kernel clock stamps.  stamps receives 8 uint64 per block: {s_memtime, s_memrealtime} at kernel
+ * entry, after the first K-step has landed, after the K loop, after the last store has drained.
+ * tools/gemm_stamps.py turns them into per-phase times and the clock the chip held. */
+int ufnd_gemm_bf16_stamps(const void* A, const void* W, void* out_bf16, int M, int N, int K, int tile_cfg,
+                          unsigned long long* stamps, void* stream);
 
 /* Split-K form for narrow-N / long-K Linears (BERT output.dense, K = 3072): K is cut into `ksplit`
  * slices, block (tile, s) writes the raw fp32 partial product of slice s to slabs[s] ((M,N), row

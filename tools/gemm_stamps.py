@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""In-kernel phase times of the bf16 GEMM (GPU box): ufnd_gemm_bf16_stamps writes s_memtime /
+s_memrealtime at kernel entry, first K-step landed, K loop done, stores drained.  Prints, per tile
+configuration and shape, the median over blocks of each phase in us (100 MHz realtime counter), the
+shader clock held inside the K loop, and the first-start -> last-end span of the whole grid.
+usage: gemm_stamps.py [--cfgs=8,22] [--shapes=bert_qkv,bert_ffn1]"""
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch
+
+from ultrafnd_git_amd import _lib as L
+from tools.gemm_sweep import SHAPES, TILES
+
+
+def main():
+    only, want = None, None
+    for a in sys.argv:
+        if a.startswith("--cfgs="):
+            only = {int(x) for x in a.split("=")[1].split(",")}
+        if a.startswith("--shapes="):
+            want = a.split("=")[1].split(",")
+    dev = "cuda"
+    for name, M, N, K in SHAPES:
+        if want and name not in want:
+            continue
+        g = torch.Generator().manual_seed(M + N)
+        A = torch.randn(M, K, generator=g).to(dev).bfloat16()
+        W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).bfloat16()
+        ob = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        print(f"== {name} M={M} N={N} K={K}: median over blocks, us")
+        for c, (bm, bn, lay) in TILES.items():
+            if N % bn or (only is not None and c not in only):
+                continue
+            nblk = -(-M // bm) * (N // bn)
+            st = torch.zeros(nblk, 8, dtype=torch.int64, device=dev)
+            rows = []
+            for it in range(12):
+                L.check(L.lib().ufnd_gemm_bf16_stamps(A.data_ptr(), W.data_ptr(), ob.data_ptr(), M, N, K, c, st.data_ptr(),
+                                                      L.stream_ptr(A.device)), "stamps")
+                torch.cuda.synchronize()
+                if it >= 4:
+                    rows.append(st.clone())
+            s = torch.stack(rows).double()              # (iters, blocks, 8)
+            rt = s[..., 1::2] * 0.01                    # realtime stamps in us
+            cy = s[..., 0::2]
+            pro = (rt[..., 1] - rt[..., 0]).median().item()
+            loop = (rt[..., 2] - rt[..., 1]).median().item()
+            epi = (rt[..., 3] - rt[..., 2]).median().item()
+            ghz = ((cy[..., 2] - cy[..., 1]) / (rt[..., 2] - rt[..., 1]).clamp_min(1e-9) * 1e-3).median().item()
+            span = (rt[..., 3].amax(1) - rt[..., 0].amin(1)).median().item()
+            skew = (rt[..., 0].amax(1) - rt[..., 0].amin(1)).median().item()
+            nk = K // 64
+            print(f"   {c}:{bm}x{bn}/{lay:10s} blocks {nblk:4d}  prologue {pro:5.2f}  loop {loop:6.2f} ({loop / nk:5.3f}/K-step, {ghz:4.2f} GHz)"
+                  f"  epilogue {epi:5.2f}  grid span {span:6.2f}  start skew {skew:5.2f}")
+
+
+if __name__ == "__main__":
+    main()

@@ -2,7 +2,7 @@
 """Sweep ufnd_gemm_bf16_ex tile configurations over the encoder GEMM shapes (GPU box).
 Interleaved rounds in ONE process (variants x rounds), median of per-launch HIP-event times minus
 the empty event-pair time, random operands.  Every variant is first checked against an fp32 torch
-matmul of the same bf16 data.   usage: gemm_sweep.py [rounds] [--ablate]"""
+matmul of the same bf16 data.   usage: gemm_sweep.py [rounds] [--ablate] [--real] [--cold] [--cfgs=8,22] [--shapes=bert_qkv,...]"""
 import json
 import sys
 from pathlib import Path
@@ -16,18 +16,41 @@ DEV = "cuda"
 SHAPES = [("bert_qkv", 4096, 2304, 768), ("bert_out", 4096, 768, 768), ("bert_ffn1", 4096, 3072, 768),
           ("bert_ffn2", 4096, 768, 3072), ("vit_qkv", 1600, 2304, 768), ("vit_out", 1600, 768, 768),
           ("vit_ffn1", 1600, 3072, 768), ("vit_ffn2", 1600, 768, 3072), ("vit_patch", 1568, 768, 3072)]
-TILES = {0: (128, 128, "2x2x3"), 1: (128, 64, "2x2x3"), 2: (256, 128, "4x2x3"), 3: (128, 128, "2x2x2"), 4: (128, 64, "2x2x4"),
-         5: (256, 64, "4x2x3"), 6: (128, 288, "2x2x3"), 7: (128, 96, "2x2x3"), 8: (256, 192, "4x2x2"), 9: (128, 384, "2x2x2"),
-         10: (128, 192, "2x2x3"), 11: (128, 96, "2x2x4"), 12: (64, 96, "1x2x4"), 13: (64, 192, "1x2x3"), 14: (128, 256, "2x2x2"),
-         15: (256, 256, "4x2x2"), 16: (128, 128, "4x2x3"), 17: (128, 192, "4x2x3"), 18: (256, 64, "4x2x4"), 19: (64, 64, "1x2x4"),
-         20: (128, 64, "4x2x4"), 21: (256, 192, "2x4x2")}
+# id -> (BM, BN, "WMxWN/ring slots A,W"): mirrors UFND_GEMM_TILES in csrc/gemm_bf16.hip
+TILES = {0: (128, 128, "2x2/3,3"), 1: (128, 64, "2x2/3,3"), 2: (256, 128, "4x2/3,3"), 3: (128, 128, "2x2/2,2"), 4: (128, 64, "2x2/4,4"),
+         5: (256, 64, "4x2/3,3"), 6: (128, 288, "2x2/3,3"), 7: (128, 96, "2x2/3,3"), 8: (256, 192, "4x2/2,2"), 9: (128, 384, "2x2/2,2"),
+         10: (128, 192, "2x2/3,3"), 11: (128, 96, "2x2/4,4"), 12: (64, 96, "1x2/4,4"), 13: (64, 192, "1x2/3,3"), 14: (128, 256, "2x2/2,2"),
+         15: (256, 256, "4x2/2,2"), 16: (128, 128, "4x2/3,3"), 17: (128, 192, "4x2/3,3"), 18: (256, 64, "4x2/4,4"), 19: (64, 64, "1x2/4,4"),
+         20: (128, 64, "4x2/4,4"), 21: (256, 192, "2x4/2,2"), 22: (256, 192, "4x2/3,2"), 23: (256, 256, "4x2/3,2"),
+         24: (128, 192, "4x2/4,4"), 25: (128, 256, "4x2/3,3"),
+         # 32x32x16 MFMA forms
+         26: (256, 192, "4x2/2,2/m32"), 27: (256, 192, "4x2/3,2/m32"), 28: (128, 128, "4x2/3,3/m32"), 29: (128, 192, "4x2/3,3/m32"),
+         30: (256, 256, "4x2/3,2/m32"), 31: (128, 64, "4x2/4,4/m32"), 32: (256, 128, "4x2/3,3/m32"), 33: (128, 64, "2x2/3,3/m32")}
 
 
 REAL = {}   # name -> (act, use_residual_and_f32_out): the epilogue each shape has in the encoders
 
 
+BASE = None   # ctypes handle of an older build of the library (--base=path): timed in the same rounds
+
+
+def _base_lib(path):
+    import ctypes as C
+    lib = C.CDLL(path)
+    P, I = C.c_void_p, C.c_int
+    lib.ufnd_gemm_bf16_ex.argtypes = [P] * 6 + [I] * 10 + [P]
+    lib.ufnd_gemm_bf16_ex.restype = I
+    return lib
+
+
 def run(cfg, A, W, bias, ob, M, N, K, name=None):
     act, res = REAL.get(name, (0, False))
+    if cfg >= 10000:     # the baseline library's tile `cfg - 10000` (its +1000 = software-pipelined schedule)
+        r, o, f = (RES.data_ptr(), None, OF.data_ptr()) if res else (None, ob.data_ptr(), None)
+        rc = BASE.ufnd_gemm_bf16_ex(A.data_ptr(), W.data_ptr(), bias.data_ptr(), r, o, f, M, N, K, K, K, N if res else 0, 0 if res else N,
+                                    N if res else 0, act, cfg - 10000, L.stream_ptr(A.device))
+        assert rc == 0, rc
+        return
     if res:
         L.check(L.lib().ufnd_gemm_bf16_ex(A.data_ptr(), W.data_ptr(), bias.data_ptr(), RES.data_ptr(), None, OF.data_ptr(), M, N, K,
                                           K, K, N, 0, N, act, cfg, L.stream_ptr(A.device)), "gemm_ex")
@@ -48,7 +71,13 @@ def empty_pair_ms():
 
 
 def main():
-    global RES, OF
+    global RES, OF, BASE
+    base_cfgs = []
+    for a in sys.argv:
+        if a.startswith("--base="):
+            BASE = _base_lib(a.split("=", 1)[1])
+        if a.startswith("--base-cfgs="):
+            base_cfgs = [int(x) for x in a.split("=")[1].split(",")]
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 5
     if "--real" in sys.argv:
         REAL.update({"bert_out": (0, True), "bert_ffn1": (1, False), "bert_ffn2": (0, True), "vit_out": (0, True),
@@ -57,29 +86,32 @@ def main():
     OF = torch.empty(4096, 3072, device=DEV)
     ablate = "--ablate" in sys.argv
     out = {}
-    for name, M, N, K in SHAPES:
+    ONLY = None
+    for a in sys.argv:
+        if a.startswith("--cfgs="):
+            ONLY = {int(x) for x in a.split("=")[1].split(",")}
+    shapes = SHAPES
+    for a in sys.argv:
+        if a.startswith("--shapes="):
+            want = a.split("=")[1].split(",")
+            shapes = [s for s in SHAPES if s[0] in want]
+    for name, M, N, K in shapes:
         g = torch.Generator().manual_seed(M + N)
         A = torch.randn(M, K, generator=g).to(DEV).bfloat16()
         W = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV).bfloat16()
         bias = torch.randn(N, generator=g).to(DEV)
         ob = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
         ref = A.float() @ W.float().t() + bias
-        cfgs = [c for c, (bm, bn, _) in TILES.items() if N % bn == 0]
+        cfgs = [c for c, (bm, bn, _) in TILES.items() if N % bn == 0 and (ONLY is None or c in ONLY)]
         for c in cfgs:
             ob.zero_()
             run(c, A, W, bias, ob, M, N, K)
             torch.cuda.synchronize()
             err = (ob.float() - ref).abs().max().item()
-            assert err <= 0.05 * max(1.0, ref.abs().max().item()), (name, c, err)
+            assert err <= 0.02 * max(1.0, ref.abs().max().item()), (name, c, err)
         variants = list(cfgs)
-        if "--sched" in sys.argv:
-            for c in cfgs:
-                ob.zero_()
-                run(1000 + c, A, W, bias, ob, M, N, K)
-                torch.cuda.synchronize()
-                err = (ob.float() - ref).abs().max().item()
-                assert err <= 0.05 * max(1.0, ref.abs().max().item()), (name, "sched", c, err)
-            variants += [1000 + c for c in cfgs]
+        if BASE is not None:
+            variants += [10000 + c for c in base_cfgs if N % TILES[c % 1000][1] == 0]
         if ablate:
             variants += [100 + c for c in cfgs] + [200 + c for c in cfgs]
         times = {c: [] for c in variants}
@@ -102,8 +134,12 @@ def main():
         for c in variants:
             t = sorted(times[c])
             med = t[len(t) // 2] * 1e-3
-            bm, bn, lay = TILES[c % 100]
-            tag = f"{c % 100}:{bm}x{bn}/{lay}" + {0: "", 1: "-noMFMA", 2: "-noDMA"}[(c % 1000) // 100] + ("-sched" if c >= 1000 else "")
+            if c >= 10000:
+                bm, bn, lay = TILES[c % 1000]
+                tag = f"BASE {c % 1000}:{bm}x{bn}" + ("-sched" if (c - 10000) >= 1000 else "")
+            else:
+                bm, bn, lay = TILES[c % 100]
+                tag = f"{c % 100}:{bm}x{bn}/{lay}" + {0: "", 1: "-noMFMA", 2: "-noDMA"}[(c % 1000) // 100]
             tiles = -(-M // bm) * (N // bn)
             row[tag] = {"us": round(med * 1e6, 2), "tflops": round(2.0 * M * N * K / med / 1e12, 1), "tiles": tiles}
         out[name] = row

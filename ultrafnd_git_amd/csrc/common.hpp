@@ -47,11 +47,13 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return cdf + x * pdf;
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// bf16-output epilogues: v_exp + v_rcp (1 ulp) instead of the IEEE division sequence
+__device__ __forceinline__ float sigmoid_fast_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // erf-GELU for bf16 outputs: Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7, far below a bf16 ulp),
 // one v_exp + one v_rcp + 7 FMAs instead of libm's erff polynomial ladder.
 __device__ __forceinline__ float gelu_fast_f(float x) {
   const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);   // v_rcp_f32 (1 ulp); __frcp_rn expands to the IEEE division ladder
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float erf_abs = 1.0f - poly * __expf(-z * z);
   return 0.5f * x * (1.0f + copysignf(erf_abs, x));

@@ -6,12 +6,15 @@
 // Operand tiles go HBM -> LDS by LDS-DMA (global_load_lds, 16 B/lane): the LDS image is
 // lane-linear, so the bank-conflict swizzle (16-B chunk ^= (row>>1)&7, conflict-free for
 // ds_read_b128 of 128-B rows) is applied to each lane's SOURCE address and to the read address.
-// ST-deep LDS ring with counted vmcnt and ONE raw s_barrier per K-step: the DMA of steps
-// t+1..t+ST-2 stays in flight across the barrier while step t is multiplied.
+// Multi-slot LDS rings with counted vmcnt and ONE raw s_barrier per K-step, placed between the two
+// k-halves of the step: the DMA of later steps stays in flight across it, and every fragment read
+// and DMA issue is overlapped with the MFMAs of the other k-half.
 // Epilogue: accumulators -> LDS (per wave) -> whole rows: bias, activation, fp32 residual,
 // 16-B bf16 and/or 32-B fp32 stores per lane (full cache lines per row).
 // Grid: one block per tile, XCD-aware (bijective) remap so that the blocks sharing an A
 // row-panel land on the same XCD's L2.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace {
@@ -28,6 +31,7 @@ struct GemmArgs {
   int M, N, K, lda, ldw, ldr, ldo, ldf, act;
   int m_tiles, n_tiles;
   int ksplit;            // > 1: block (tile, s) multiplies K-slice s and writes raw fp32 partials to slab s
+  unsigned long long* stamps;   // DBG builds only
 };
 
 __device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst) {
@@ -46,30 +50,48 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // BM x BN x 64 block tile, WM x WN waves, wave tile (BM/WM) x (BN/WN).  The A rows and the W rows of
-// a K-step form ONE list of (BM+BN)/8 1-KiB DMA pieces dealt round-robin to the waves, so every
-// wave has exactly PW pieces per stage in flight and a counted s_waitcnt vmcnt is exact.
-// ST-deep LDS ring:
-//   step t:  wait (my pieces of stage t landed; stages t+1.. stay in flight)  ->  ONE s_barrier
-//            (everyone's pieces landed, and everyone is done reading stage t-1)  ->  issue stage
-//            t+ST-1 into the buffer stage t-1 used  ->  multiply stage t.
-// ABL (timing experiments only, results are garbage): 1 = no MFMA/LDS reads, 2 = no DMA in the loop
-// SCH: 0 = compiler's schedule; 1 = explicit: both k-halves' fragment reads issued first (the second
-// half lands while the first half multiplies), then the stage's DMA pieces spread between MFMA groups.
-template <int BM, int BN, int WM, int WN, int ST, int ABL = 0, int SCH = 0>
+// a K-step are two lists of 1-KiB DMA pieces, each dealt round-robin to the waves, so every wave has
+// exactly PWA + PWB pieces per K-step in flight and a counted s_waitcnt vmcnt is exact.
+// Two LDS rings, STA slots of the A tile and STB slots of the W tile (STA == STB or STA == STB + 1:
+// where three whole stages do not fit in 160 KiB the A operand still runs one K-step further ahead).
+// Every slot is filled before the loop; the loop's ONE s_barrier per K-step sits in the MIDDLE of the
+// step (see body below), where it both certifies step t+1 and frees step t's slots for refilling.
+// ABL (timing experiments only, results are garbage): 1 = no MFMA/LDS reads, 2 = no DMA in the loop.
+// DBG = 1: lane 0 of every block also writes s_memtime / s_memrealtime stamps (entry, first stage
+// landed, main loop done, end) to a.stamps[16 * block .. ] -- diagnostics builds only.
+template <int V> struct IntC { static constexpr int value = V; };
+
+// MI = 16: v_mfma_f32_16x16x32_bf16 (one fragment read feeds 32 k of a 16-row tile);
+// MI = 32: v_mfma_f32_32x32x16_bf16 (lane l: row l&31, k = 8(l>>5)+j; half as many matrix
+//          instructions per K-step, so the SIMD's vector issue is held half as long).
+template <int BM, int BN, int WM, int WN, int STA, int STB, int MI, int ABL = 0, int DBG = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs a) {
+  static_assert(MI == 16 || MI == 32, "MFMA shape");
+  using acc_t = typename std::conditional<MI == 16, f32x4, f32x16>::type;
+  constexpr int AR = MI * MI / 64;               // accumulator registers per MFMA tile
+  constexpr int KQ = MI == 16 ? 1 : 2;           // MFMA k-steps per k-half (32 k)
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN;      // wave tile
-  constexpr int MT = TM / 16, NT = TN / 16;      // MFMA tiles per wave
-  constexpr int STAGE = (BM + BN) * 128;
-  constexpr int PIECES = (BM + BN) / 8;
-  constexpr int PW = PIECES / NW;                // DMA wave-instructions per wave per stage
-  constexpr int CP = TN + 4;                     // fp32 C-staging pitch (floats), 16 rows per wave
-  constexpr int CBYTES = NW * 16 * CP * 4;
-  constexpr int SMEM = (ST * STAGE > CBYTES) ? ST * STAGE : CBYTES;
+  constexpr int MT = TM / MI, NT = TN / MI;      // MFMA tiles per wave
+  constexpr int ASLOT = BM * 128, BSLOT = BN * 128;
+  constexpr int DA = STA - 1, DB = STB - 1;      // K-steps of lookahead per operand
+  constexpr int PWA = BM / 8 / NW, PWB = BN / 8 / NW;   // DMA wave-instructions per wave per K-step
+  constexpr int WAITN = PWA * (DA - 1 > 0 ? DA - 1 : 0) + PWB * (DB - 1 > 0 ? DB - 1 : 0);
+  constexpr int CP = TN + 4;                     // fp32 C-staging pitch (floats), MI rows per wave
+  constexpr int CBYTES = NW * MI * CP * 4;
+  constexpr int RING = STA * ASLOT + STB * BSLOT;
+  constexpr int SMEM = (RING > CBYTES) ? RING : CBYTES;
   static_assert(SMEM <= 160 * 1024, "LDS budget");
-  static_assert(PIECES % NW == 0 && TM % 16 == 0 && TN % 16 == 0 && BM % 8 == 0 && BN % 8 == 0, "tile split");
-  static_assert(PW * (ST - 2 > 0 ? ST - 2 : 0) <= 63, "vmcnt range");
+  static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0 && TM % MI == 0 && TN % MI == 0, "tile split");
+  static_assert(STB >= 2 && (STA == STB || STA == STB + 1), "ring depths");
+  static_assert(WAITN <= 63, "vmcnt range");
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
+
+  unsigned long long stamp[8];
+  if constexpr (DBG) {
+    stamp[0] = __builtin_amdgcn_s_memtime();
+    stamp[1] = __builtin_amdgcn_s_memrealtime();
+  }
 
   // XCD-aware bijective remap of the block id
   const int nblk = a.m_tiles * a.n_tiles * a.ksplit;
@@ -82,163 +104,224 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
   bid /= a.ksplit;
   const int m0 = (bid / a.n_tiles) * BM, n0 = (bid % a.n_tiles) * BN;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int wm = wave / WN, wn = wave % WN, fr = lane & 15, g = lane >> 4;
+  const int wm = wave / WN, wn = wave % WN, fr = lane & (MI - 1), g = lane / MI;   // fragment row, k-group
 
-  f32x4 acc[MT][NT];
+  acc_t acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < AR; ++r) acc[i][j][r] = 0.f;
 
   const int nk = a.K / BK / a.ksplit;         // K-steps of this block's slice
   const int kbase = ks * nk * BK;
-  auto issue = [&](int t) {
-    char* buf = smem + (t % ST) * STAGE;
+  // per-lane source rows of my pieces (fixed over the K loop): only the column offset moves
+  const int prow = lane >> 3, ppos = lane & 7;
+  auto issueA = [&](int t) {
+    char* buf = smem + (t % STA) * ASLOT;
     const int k0 = kbase + t * BK;
 #pragma unroll
-    for (int ii = 0; ii < PW; ++ii) {
-      const int p = wave + NW * ii;                  // piece id: rows 8p..8p+7 of [A tile ; W tile]
-      const int r = 8 * p + (lane >> 3), pos = lane & 7;
-      const int c = pos ^ ((r >> 1) & 7);            // (BM % 16 == 0 keeps the swizzle phase per tile)
-      const __bf16* src;
-      if (p < BM / 8) {
-        int gr = m0 + r;
-        gr = gr < a.M ? gr : a.M - 1;
-        src = a.A + (size_t)gr * a.lda + k0 + c * 8;
-      } else {
-        int gr = n0 + (r - BM);
-        gr = gr < a.N ? gr : a.N - 1;
-        src = a.W + (size_t)gr * a.ldw + k0 + c * 8;
-      }
-      dma16(src, buf + p * 1024);
+    for (int ii = 0; ii < PWA; ++ii) {
+      const int p = wave + NW * ii;                  // piece id: rows 8p..8p+7 of the A tile
+      const int r = 8 * p + prow;
+      const int c = ppos ^ ((r >> 1) & 7);
+      int gr = m0 + r;
+      gr = gr < a.M ? gr : a.M - 1;
+      dma16(a.A + (size_t)gr * a.lda + k0 + c * 8, buf + p * 1024);
     }
   };
+  auto issueB = [&](int t) {
+    char* buf = smem + STA * ASLOT + (t % STB) * BSLOT;
+    const int k0 = kbase + t * BK;
 #pragma unroll
-  for (int t = 0; t < ST - 1; ++t)
-    if (t < nk) issue(t);
+    for (int ii = 0; ii < PWB; ++ii) {
+      const int p = wave + NW * ii;
+      const int r = 8 * p + prow;
+      const int c = ppos ^ ((r >> 1) & 7);
+      int gr = n0 + r;
+      gr = gr < a.N ? gr : a.N - 1;
+      dma16(a.W + (size_t)gr * a.ldw + k0 + c * 8, buf + p * 1024);
+    }
+  };
+  // prologue: every ring slot is filled (W(s) before A(s), step by step, so that a counted vmcnt
+  // separates "steps <= t+1" from the later ones)
+#pragma unroll
+  for (int s = 0; s < STA; ++s) {
+    if (s < STB && s < nk) issueB(s);
+    if (s < nk) issueA(s);
+  }
 
-  for (int t = 0; t < nk; ++t) {
-    // stages issued so far: min(nk, t + ST - 1); those after t may stay in flight
-    if (t + ST - 1 <= nk) wait_vmcnt<PW*(ST - 2 > 0 ? ST - 2 : 0)>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    const char* At = smem + (t % ST) * STAGE;
-    const char* Bt = At + BM * 128;
-    if constexpr (SCH == 0 || ABL != 0) {
-      if (ABL != 2 && t + ST - 1 < nk) issue(t + ST - 1);
+  bf16x8 af0[KQ][MT], bf0[KQ][NT], af1[KQ][MT], bf1[KQ][NT];      // fragments of k-half 0 / k-half 1
+  auto read_half = [&](int t, auto kk_, bf16x8 (&af)[KQ][MT], bf16x8 (&bfr)[KQ][NT]) {
+    constexpr int kk = decltype(kk_)::value;
+    const char* At = smem + (t % STA) * ASLOT;
+    const char* Bt = smem + STA * ASLOT + (t % STB) * BSLOT;
 #pragma unroll
-      for (int kk = 0; kk < (ABL == 1 ? 0 : 2); ++kk) {
-        bf16x8 af[MT], bfr[NT];
+    for (int q = 0; q < KQ; ++q) {
+      const int chunk = MI == 16 ? g + 4 * kk : g + 2 * q + 4 * kk;     // 16-B chunk of the 128-B row
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = lds_frag(At, wm * TM + i * 16 + fr, g + 4 * kk);
+      for (int i = 0; i < MT; ++i) af[q][i] = lds_frag(At, wm * TM + i * MI + fr, chunk);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bfr[j] = lds_frag(Bt, wn * TN + j * 16 + fr, g + 4 * kk);
+      for (int j = 0; j < NT; ++j) bfr[q][j] = lds_frag(Bt, wn * TN + j * MI + fr, chunk);
+    }
+  };
+  auto mma_half = [&](const bf16x8 (&af)[KQ][MT], const bf16x8 (&bfr)[KQ][NT]) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+    for (int q = 0; q < KQ; ++q)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          if constexpr (MI == 16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[q][i], bfr[q][j], acc[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[q][i], bfr[q][j], acc[i][j], 0, 0, 0);
+        }
+  };
+  // step t (its k-half-0 fragments are already in registers):
+  //   k-half-1 fragment reads || MFMAs of k-half 0
+  //   wait: my pieces of step t+1 landed, my reads of step t retired  ->  ONE s_barrier (step t+1 is
+  //   complete in LDS; nobody reads step t's slots any more)
+  //   refill step t's slots with W(t+STB), A(t+STA); k-half-0 reads of step t+1 || MFMAs of k-half 1
+  // so every LDS read and every DMA issue sits beside MFMAs of the other half, and the barrier has
+  // half a step of queued matrix work on either side.  One MFMA leads each half so that the wait the
+  // compiler places in front of it covers only reads issued half a step earlier.
+  constexpr int NMF = KQ * MT * NT, NRD = KQ * (MT + NT);
+  auto body = [&](int t, auto ia_, auto ib_, auto next_) {
+    constexpr bool IA = decltype(ia_)::value != 0, IB = decltype(ib_)::value != 0, NEXT = decltype(next_)::value != 0;
+    if constexpr (ABL != 1) {
+      read_half(t, IntC<1>{}, af1, bf1);
+      mma_half(af0, bf0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1, 0);
+    }
+    if constexpr (NEXT) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + STA - 1 < nk) wait_vmcnt<WAITN>();    // steps t+2 .. may stay in flight (all exist while t+STA-1 < nk)
+      else wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // (reads first in program order: the DMA writes other slots, but the compiler cannot know and
+      //  would keep every LDS read behind the last DMA)
+      if constexpr (ABL != 1) read_half(t + 1, IntC<0>{}, af0, bf0);
+      if constexpr (ABL != 2) {
+        if constexpr (IB) issueB(t + STB);
+        if constexpr (IA) issueA(t + STA);
       }
-    } else {
-      bf16x8 af[2][MT], bfr[2][NT];
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i) af[kk][i] = lds_frag(At, wm * TM + i * 16 + fr, g + 4 * kk);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bfr[kk][j] = lds_frag(Bt, wn * TN + j * 16 + fr, g + 4 * kk);
-      }
-      if (t + ST - 1 < nk) issue(t + ST - 1);
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
-      // shape of the emitted stream: all 2(MT+NT) LDS reads, then {G MFMAs, 1 DMA piece} x PW, then the rest
-      constexpr int NMF = 2 * MT * NT, GRP = NMF / (PW + 1) > 0 ? NMF / (PW + 1) : 1;
-      __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MT + NT), 0);
+    }
+    if constexpr (ABL != 1) {
+      mma_half(af1, bf1);
+      constexpr int PW = (ABL == 2 || !NEXT) ? 0 : (IA ? PWA : 0) + (IB ? PWB : 0);
+      constexpr int GRP = (NMF - 1) / (PW + 1) > 0 ? (NMF - 1) / (PW + 1) : 1;
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if constexpr (NEXT) __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
 #pragma unroll
       for (int q = 0; q < PW; ++q) {
         __builtin_amdgcn_sched_group_barrier(0x008, GRP, 0);
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, NMF - GRP * PW > 0 ? NMF - GRP * PW : 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1 - GRP * PW > 0 ? NMF - 1 - GRP * PW : 0, 0);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this step's LDS reads retired before the next barrier
+  };
+
+  // stage 0 landed (everything issued after it may stay in flight when it all exists)
+  if (STA <= nk) wait_vmcnt<PWA * (STA - 1) + PWB * (STB - 1)>();
+  else wait_vmcnt<0>();
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (DBG) {
+    stamp[2] = __builtin_amdgcn_s_memtime();
+    stamp[3] = __builtin_amdgcn_s_memrealtime();
   }
+  if constexpr (ABL != 1) read_half(0, IntC<0>{}, af0, bf0);
+  int t = 0;
+  for (; t + STA < nk; ++t) body(t, IntC<1>{}, IntC<1>{}, IntC<1>{});     // steady state
+  for (; t + STB < nk; ++t) body(t, IntC<0>{}, IntC<1>{}, IntC<1>{});     // (STA == STB + 1) only W left to fetch
+  for (; t + 1 < nk; ++t) body(t, IntC<0>{}, IntC<0>{}, IntC<1>{});       // drain
+  body(t, IntC<0>{}, IntC<0>{}, IntC<0>{});                               // last step: no successor
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();   // everyone is done reading the ring: reuse it for the epilogue
   __builtin_amdgcn_sched_barrier(0);
+  if constexpr (DBG) {
+    stamp[4] = __builtin_amdgcn_s_memtime();
+    stamp[5] = __builtin_amdgcn_s_memrealtime();
+  }
 
   // ---- epilogue.  Bias and activation are elementwise, so they run on the accumulators where they
   // lie (straight-line VALU, no LDS dependency); only the layout change for whole-row stores goes
   // through a wave-private LDS patch, 16 rows at a time, where the fp32 residual is added.
+  float bj[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) bj[j] = 0.f;
   if (a.bias) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const float bj = a.bias[n0 + wn * TN + j * 16 + fr];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) acc[i][j] += bj;
-    }
+    for (int j = 0; j < NT; ++j) bj[j] = a.bias[n0 + wn * TN + j * MI + fr];
   }
-  if (a.act == UFND_ACT_GELU) {
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] = gelu_fast_f(acc[i][j][r]);
-  } else if (a.act == UFND_ACT_QUICK_GELU) {
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] = acc[i][j][r] * sigmoid_f(1.702f * acc[i][j][r]);
-  }
-  float* cst = reinterpret_cast<float*>(smem) + wave * 16 * CP;
+  float* cst = reinterpret_cast<float*>(smem) + wave * MI * CP;
   constexpr int CPR = TN / 8;                    // 8-column chunks per row
-  constexpr int CHUNKS = 16 * CPR;               // chunks per 16-row patch
+  constexpr int CHUNKS = MI * CPR;               // chunks per MI-row patch
+  auto epilogue = [&](auto act_) {
+    constexpr int ACT = decltype(act_)::value;
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
+    for (int i = 0; i < MT; ++i) {
+      // bias + activation of row-tile i on the accumulators (VALU), beside the stores of row-tile i-1
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) cst[(4 * g + r) * CP + j * 16 + fr] = acc[i][j][r];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int r = 0; r < AR; ++r) {
+          float v = acc[i][j][r] + bj[j];
+          if constexpr (ACT == UFND_ACT_GELU) v = gelu_fast_f(v);
+          else if constexpr (ACT == UFND_ACT_QUICK_GELU) v = v * sigmoid_fast_f(1.702f * v);
+          // accumulator register r of lane (fr, g): 16x16 -> row 4g + r; 32x32 -> row 8(r>>2) + 4g + (r&3)
+          const int prow_ = MI == 16 ? 4 * g + r : 8 * (r >> 2) + 4 * g + (r & 3);
+          cst[prow_ * CP + j * MI + fr] = v;
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int it = 0; it < (CHUNKS + 63) / 64; ++it) {
-      const int id = lane + 64 * it;
-      if (id >= CHUNKS) break;
-      const int rr = id / CPR, cl = (id % CPR) * 8;
-      const int row = m0 + wm * TM + i * 16 + rr;
-      const int col = n0 + wn * TN + cl;
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(cst + rr * CP + cl);
-      const f32x4 v1 = *reinterpret_cast<const f32x4*>(cst + rr * CP + cl + 4);
-      if (row >= a.M) continue;
-      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-      if (a.residual) {
-        const float* rp = a.residual + (size_t)row * a.ldr + col;
-        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+      for (int it = 0; it < (CHUNKS + 63) / 64; ++it) {
+        const int id = lane + 64 * it;
+        if (id >= CHUNKS) break;
+        const int rr = id / CPR, cl = (id % CPR) * 8;
+        const int row = m0 + wm * TM + i * MI + rr;
+        const int col = n0 + wn * TN + cl;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(cst + rr * CP + cl);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(cst + rr * CP + cl + 4);
+        if (row >= a.M) continue;
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        if (a.residual) {
+          const float* rp = a.residual + (size_t)row * a.ldr + col;
+          const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { v[q] += r0[q]; v[4 + q] += r1[q]; }
+          for (int q = 0; q < 4; ++q) { v[q] += r0[q]; v[4 + q] += r1[q]; }
+        }
+        if (a.out_f32) {
+          float* op = a.out_f32 + (size_t)ks * a.M * a.ldf + (size_t)row * a.ldf + col;
+          *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        }
+        if (a.out_bf16) {
+          bf16x8 o;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) o[q] = (__bf16)v[q];
+          *reinterpret_cast<bf16x8*>(a.out_bf16 + (size_t)row * a.ldo + col) = o;
+        }
       }
-      if (a.out_f32) {
-        float* op = a.out_f32 + (size_t)ks * a.M * a.ldf + (size_t)row * a.ldf + col;
-        *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
-        *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
-      }
-      if (a.out_bf16) {
-        bf16x8 o;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) o[q] = (__bf16)v[q];
-        *reinterpret_cast<bf16x8*>(a.out_bf16 + (size_t)row * a.ldo + col) = o;
-      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // patch reads done before the next row-tile overwrites it
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // patch reads done before the next row-tile overwrites it
+  };
+  if (a.act == UFND_ACT_GELU) epilogue(IntC<UFND_ACT_GELU>{});
+  else if (a.act == UFND_ACT_QUICK_GELU) epilogue(IntC<UFND_ACT_QUICK_GELU>{});
+  else epilogue(IntC<UFND_ACT_NONE>{});
+  if constexpr (DBG) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp[6] = __builtin_amdgcn_s_memtime();
+    stamp[7] = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a.stamps[(size_t)blockIdx.x * 8 + i] = stamp[i];
+    }
   }
 }
 
@@ -256,93 +339,88 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* src, __bf16
 
 }  // namespace
 
-// tile configurations (BM x BN, waves WM x WN, LDS stages).  Exact-fit widths exist because a
-// 256-CU chip wants ~256 (or 512 at 2 blocks/CU) equal tiles per launch, not "as many as it takes".
+// tile configurations (BM x BN, waves WM x WN, LDS ring slots of A / W).  Exact-fit widths exist
+// because a 256-CU chip wants ~256 (or 512 at 2 blocks/CU) equal tiles per launch, not "as many as
+// it takes".  X(id, BM, BN, WM, WN, STA, STB, MI)
+#define UFND_GEMM_TILES(X)                                                                             \
+  X(0, 128, 128, 2, 2, 3, 3, 16)   /*  96 KiB */                                                           \
+  X(1, 128, 64, 2, 2, 3, 3, 16)    /*  72 KiB (2 blocks/CU) */                                             \
+  X(2, 256, 128, 4, 2, 3, 3, 16)   /* 144 KiB */                                                           \
+  X(3, 128, 128, 2, 2, 2, 2, 16)   /*  64 KiB (2 blocks/CU) */                                             \
+  X(4, 128, 64, 2, 2, 4, 4, 16)    /*  96 KiB */                                                           \
+  X(5, 256, 64, 4, 2, 3, 3, 16)    /* 120 KiB */                                                           \
+  X(6, 128, 288, 2, 2, 3, 3, 16)   /* 156 KiB (N=2304 -> 8 column tiles) */                                \
+  X(7, 128, 96, 2, 2, 3, 3, 16)    /*  84 KiB (N=768 -> 8 column tiles) */                                 \
+  X(8, 256, 192, 4, 2, 2, 2, 16)   /* 112 KiB (N=3072 -> 16 column tiles) */                               \
+  X(9, 128, 384, 2, 2, 2, 2, 16)   /* 128 KiB */                                                           \
+  X(10, 128, 192, 2, 2, 3, 3, 16)  /* 120 KiB */                                                           \
+  X(11, 128, 96, 2, 2, 4, 4, 16)   /* 112 KiB */                                                           \
+  X(12, 64, 96, 1, 2, 4, 4, 16)    /*  80 KiB (2 blocks/CU; ViT M=1600 -> 25 row tiles) */                 \
+  X(13, 64, 192, 1, 2, 3, 3, 16)   /*  96 KiB */                                                           \
+  X(14, 128, 256, 2, 2, 2, 2, 16)  /*  96 KiB */                                                           \
+  X(15, 256, 256, 4, 2, 2, 2, 16)  /* 128 KiB */                                                           \
+  X(16, 128, 128, 4, 2, 3, 3, 16)  /*  96 KiB (8 waves, wave tile 32x64) */                                \
+  X(17, 128, 192, 4, 2, 3, 3, 16)  /* 120 KiB (8 waves, wave tile 32x96) */                                \
+  X(18, 256, 64, 4, 2, 4, 4, 16)   /* 160 KiB */                                                           \
+  X(19, 64, 64, 1, 2, 4, 4, 16)    /*  64 KiB (2 blocks/CU) */                                             \
+  X(20, 128, 64, 4, 2, 4, 4, 16)   /*  96 KiB (8 waves, wave tile 32x32) */                                \
+  X(21, 256, 192, 2, 4, 2, 2, 16)  /* 112 KiB (wave tile 128x48) */                                        \
+  X(22, 256, 192, 4, 2, 3, 2, 16)  /* 144 KiB: A two K-steps ahead, W one */                               \
+  X(23, 256, 256, 4, 2, 3, 2, 16)  /* 160 KiB */                                                           \
+  X(24, 128, 192, 4, 2, 4, 4, 16)  /* 160 KiB */                                                           \
+  X(25, 128, 256, 4, 2, 3, 3, 16)  /* 144 KiB (8 waves, wave tile 32x128) */                               \
+  X(26, 256, 192, 4, 2, 2, 2, 32)  /* 32x32x16 MFMA forms */                                              \
+  X(27, 256, 192, 4, 2, 3, 2, 32)                                                                      \
+  X(28, 128, 128, 4, 2, 3, 3, 32)                                                                      \
+  X(29, 128, 192, 4, 2, 3, 3, 32)                                                                      \
+  X(30, 256, 256, 4, 2, 3, 2, 32)                                                                      \
+  X(31, 128, 64, 4, 2, 4, 4, 32)                                                                       \
+  X(32, 256, 128, 4, 2, 3, 3, 32)                                                                      \
+  X(33, 128, 64, 2, 2, 3, 3, 32)   /* 2 blocks/CU */
+
 struct TileCfg { int bm, bn, threads; };
 static const TileCfg kTiles[] = {
-    {128, 128, 256},  //  0: 128x128 2x2 3-stage   96 KiB
-    {128, 64, 256},   //  1: 128x64  2x2 3-stage   72 KiB (2 blocks/CU)
-    {256, 128, 512},  //  2: 256x128 4x2 3-stage  144 KiB
-    {128, 128, 256},  //  3: 128x128 2x2 2-stage   64 KiB (2 blocks/CU)
-    {128, 64, 256},   //  4: 128x64  2x2 4-stage   96 KiB
-    {256, 64, 512},   //  5: 256x64  4x2 3-stage  120 KiB
-    {128, 288, 256},  //  6: 128x288 2x2 3-stage  156 KiB  (N=2304 -> 8 column tiles)
-    {128, 96, 256},   //  7: 128x96  2x2 3-stage   84 KiB  (N=768 -> 8 column tiles)
-    {256, 192, 512},  //  8: 256x192 4x2 2-stage  112 KiB  (N=3072 -> 16 column tiles)
-    {128, 384, 256},  //  9: 128x384 2x2 2-stage  128 KiB  (N=3072 -> 8 column tiles)
-    {128, 192, 256},  // 10: 128x192 2x2 3-stage  120 KiB
-    {128, 96, 256},   // 11: 128x96  2x2 4-stage  112 KiB
-    {64, 96, 128},    // 12: 64x96   1x2 4-stage   80 KiB  (2 blocks/CU; ViT M=1600 -> 25 row tiles)
-    {64, 192, 128},   // 13: 64x192  1x2 3-stage   96 KiB
-    {128, 256, 256},  // 14: 128x256 2x2 2-stage   96 KiB
-    {256, 256, 512},  // 15: 256x256 4x2 2-stage  128 KiB
-    {128, 128, 512},  // 16: 128x128 4x2 3-stage   96 KiB (8 waves, wave tile 32x64)
-    {128, 192, 512},  // 17: 128x192 4x2 3-stage  120 KiB (8 waves, wave tile 32x96)
-    {256, 64, 512},   // 18: 256x64  4x2 4-stage  160 KiB
-    {64, 64, 128},    // 19: 64x64   1x2 4-stage   64 KiB (2 blocks/CU)
-    {128, 64, 512},   // 20: 128x64  4x2 4-stage   96 KiB (8 waves, wave tile 32x32)
-    {256, 192, 512},  // 21: 256x192 2x4 2-stage  112 KiB (wave tile 128x48)
+#define X(id, BM_, BN_, WM_, WN_, SA_, SB_, MI_) {BM_, BN_, WM_ * WN_ * 64},
+    UFND_GEMM_TILES(X)
+#undef X
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
-static int launch_cfg(int cfg, int abl, int sch, GemmArgs& a, hipStream_t stream) {
+static int launch_cfg(int cfg, int abl, GemmArgs& a, hipStream_t stream) {
   const TileCfg& t = kTiles[cfg];
   a.m_tiles = ufnd_cdiv(a.M, t.bm);
   a.n_tiles = a.N / t.bn;
   const dim3 grid(a.m_tiles * a.n_tiles * a.ksplit), block(t.threads);
-#define GO(BM_, BN_, WM_, WN_, ST_)                                                                               \
-  do {                                                                                                              \
-    if (abl == 0 && sch == 1) hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, ST_, 0, 1>), grid, block, 0, stream, a); \
-    else if (abl == 0) hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, ST_, 0>), grid, block, 0, stream, a);   \
-    else if (abl == 1) hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, ST_, 1>), grid, block, 0, stream, a); \
-    else hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, ST_, 2>), grid, block, 0, stream, a);           \
-  } while (0)
+#define X(id, BM_, BN_, WM_, WN_, SA_, SB_, MI_)                                                                   \
+  case id:                                                                                                          \
+    if constexpr (SA_ * BM_ * 128 + SB_ * BN_ * 128 <= 160 * 1024) {                                                \
+      if (abl == 0) hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, SA_, SB_, MI_, 0, 0>), grid, block, 0, stream, a);      \
+      else if (abl == 1) hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, SA_, SB_, MI_, 1, 0>), grid, block, 0, stream, a); \
+      else if (abl == 2) hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, SA_, SB_, MI_, 2, 0>), grid, block, 0, stream, a); \
+      else hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, SA_, SB_, MI_, 0, 1>), grid, block, 0, stream, a);   \
+    }                                                                                                               \
+    break;
   switch (cfg) {
-    case 0: GO(128, 128, 2, 2, 3); break;
-    case 1: GO(128, 64, 2, 2, 3); break;
-    case 2: GO(256, 128, 4, 2, 3); break;
-    case 3: GO(128, 128, 2, 2, 2); break;
-    case 4: GO(128, 64, 2, 2, 4); break;
-    case 5: GO(256, 64, 4, 2, 3); break;
-    case 6: GO(128, 288, 2, 2, 3); break;
-    case 7: GO(128, 96, 2, 2, 3); break;
-    case 8: GO(256, 192, 4, 2, 2); break;
-    case 9: GO(128, 384, 2, 2, 2); break;
-    case 10: GO(128, 192, 2, 2, 3); break;
-    case 11: GO(128, 96, 2, 2, 4); break;
-    case 12: GO(64, 96, 1, 2, 4); break;
-    case 13: GO(64, 192, 1, 2, 3); break;
-    case 14: GO(128, 256, 2, 2, 2); break;
-    case 15: GO(256, 256, 4, 2, 2); break;
-    case 16: GO(128, 128, 4, 2, 3); break;
-    case 17: GO(128, 192, 4, 2, 3); break;
-    case 18: GO(256, 64, 4, 2, 4); break;
-    case 19: GO(64, 64, 1, 2, 4); break;
-    case 20: GO(128, 64, 4, 2, 4); break;
-    case 21: GO(256, 192, 2, 4, 2); break;
+    UFND_GEMM_TILES(X)
     default: ufnd_set_error("gemm_bf16: unknown tile config %d", cfg); return UFND_ERR_INVALID;
   }
-#undef GO
+#undef X
   return UFND_OK;
 }
 
-// Per-shape choice from the on-device sweep (tools/gemm_sweep.py, profiles/r01_gemm_sweep.md):
-// a launch wants about one equal tile per CU (256) -- or per LDS slot at 2 blocks/CU -- and the
-// largest tile that still gives that many, because L2->LDS traffic falls as 1/BM + 1/BN.
+// Per-shape choice from the on-device sweep (tools/gemm_sweep.py, profiles/r01_gemm_sweep.txt):
+// a launch wants about one equal tile per CU (256), and the largest tile that still gives that
+// many, because L2->LDS traffic falls as 1/BM + 1/BN; 8-wave workgroups throughout (two waves per
+// SIMD keep the matrix pipe fed across the mid-step barrier).
 static int auto_cfg(int M, int N, int K) {
   auto tiles = [&](int cfg) { return (long long)ufnd_cdiv(M, kTiles[cfg].bm) * (N / kTiles[cfg].bn); };
-  if (N % 192 == 0 && tiles(8) >= 160) return 8;      // 256x192, 8 waves: BERT QKV (192 tiles) / FFN1 (256)
-  if (N >= 2048) {                                     // wide N, fewer rows (ViT QKV / FFN1): 8 waves, 32-row wave tiles
+  if (N % 192 == 0 && tiles(8) >= 160) return 8;      // 256x192: BERT QKV (192 tiles) / FFN1 (256)
+  if (N >= 2048) {                                     // wide N, fewer rows (ViT QKV / FFN1): 32-row wave tiles
     if (N % 192 == 0 && N >= 3072) return 17;          //   128x192
     if (N % 128 == 0) return 16;                       //   128x128
   }
-  if (K >= 2048) {                                     // narrow N, long K (FFN2 / patch embedding)
-    if (N % 96 == 0 && tiles(12) >= 400) return 12;    //   64x96 4-stage, 2 blocks/CU
-    return 20;                                         //   128x64 8 waves 4-stage
-  }
-  if (N % 128 == 0 && tiles(16) >= 150) return 16;     // out-proj at M=4096: 128x128 8 waves
-  if (N % 96 == 0) return 12;                          // small out-proj: 64x96
-  return 1;                                            // 128x64 3-stage, 2 blocks/CU
+  if (N % 128 == 0 && tiles(16) >= 150) return 16;     // narrow N at M=4096 (attention out-proj, output.dense): 128x128
+  return 20;                                           // small problems (ViT out-proj / FFN2 / patch embedding): 128x64, 4-slot ring
 }
 
 extern "C" int ufnd_gemm_bf16_ex(const void* A, const void* W, const float* bias, const float* residual, void* out_bf16,
@@ -357,15 +435,13 @@ extern "C" int ufnd_gemm_bf16_ex(const void* A, const void* W, const float* bias
   UFND_REQUIRE(!out_bf16 || (ldo % 8 == 0 && ldo >= N && ufnd_aligned(out_bf16, 16)), "gemm_bf16: out_bf16 alignment");
   UFND_REQUIRE(!bias || ufnd_aligned(bias, 4), "gemm_bf16: bias alignment");
   UFND_REQUIRE(act >= 0 && act <= 2, "gemm_bf16: act=%d", act);
-  GemmArgs a{(const __bf16*)A, (const __bf16*)W, bias, residual, (__bf16*)out_bf16, out_f32, M, N, K, lda, ldw, ldr, ldo, ldf, act, 0, 0, 1};
+  GemmArgs a{(const __bf16*)A, (const __bf16*)W, bias, residual, (__bf16*)out_bf16, out_f32, M, N, K, lda, ldw, ldr, ldo, ldf, act, 0, 0, 1, nullptr};
   // tile_cfg >= 0: explicit tile; +100 / +200 select the timing-only ablations (no MFMA / no in-loop DMA)
-  // automatic choice uses the explicit software-pipelined schedule (5-12 % faster on every shape swept)
-  int abl = 0, sch = tile_cfg < 0 ? 1 : 0, cfg = tile_cfg < 0 ? auto_cfg(M, N, K) : tile_cfg;
-  if (cfg >= 1000) { sch = 1; cfg -= 1000; }       // +1000: explicit software-pipelined schedule
+  int abl = 0, cfg = tile_cfg < 0 ? auto_cfg(M, N, K) : tile_cfg;
   if (cfg >= 200) { abl = 2; cfg -= 200; } else if (cfg >= 100) { abl = 1; cfg -= 100; }
   UFND_REQUIRE(cfg < kNumTiles, "gemm_bf16: unknown tile config %d", cfg);
   UFND_REQUIRE(N % kTiles[cfg].bn == 0, "gemm_bf16: tile config %d needs N %% %d == 0", cfg, kTiles[cfg].bn);
-  int rc = launch_cfg(cfg, abl, sch, a, (hipStream_t)stream_);
+  int rc = launch_cfg(cfg, abl, a, (hipStream_t)stream_);
   if (rc != UFND_OK) return rc;
   UFND_CHECK_LAUNCH();
   return UFND_OK;
@@ -378,11 +454,23 @@ extern "C" int ufnd_gemm_bf16_splitk(const void* A, const void* W, float* slabs,
   UFND_REQUIRE(M >= 1 && N >= 64 && N % 64 == 0, "gemm_bf16_splitk: M=%d N=%d", M, N);
   UFND_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K && ufnd_aligned(A, 16) && ufnd_aligned(W, 16) && ufnd_aligned(slabs, 16),
                "gemm_bf16_splitk: alignment");
-  GemmArgs a{(const __bf16*)A, (const __bf16*)W, nullptr, nullptr, nullptr, slabs, M, N, K, lda, ldw, 0, 0, N, 0, 0, 0, ksplit};
+  GemmArgs a{(const __bf16*)A, (const __bf16*)W, nullptr, nullptr, nullptr, slabs, M, N, K, lda, ldw, 0, 0, N, 0, 0, 0, ksplit, nullptr};
   int cfg = tile_cfg < 0 ? 17 : tile_cfg;     // 128x192, 8 waves
   if (N % kTiles[cfg < kNumTiles ? cfg : 0].bn != 0) cfg = 1;
   UFND_REQUIRE(cfg < kNumTiles && N % kTiles[cfg].bn == 0, "gemm_bf16_splitk: tile config %d does not divide N=%d", cfg, N);
-  int rc = launch_cfg(cfg, 0, 1, a, (hipStream_t)stream_);
+  int rc = launch_cfg(cfg, 0, a, (hipStream_t)stream_);
+  if (rc != UFND_OK) return rc;
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}
+
+extern "C" int ufnd_gemm_bf16_stamps(const void* A, const void* W, void* out_bf16, int M, int N, int K, int tile_cfg,
+                                     unsigned long long* stamps, void* stream_) {
+  UFND_REQUIRE(A && W && out_bf16 && stamps, "gemm_bf16_stamps: null operand");
+  UFND_REQUIRE(M >= 1 && N >= 64 && K >= 64 && N % 64 == 0 && K % 64 == 0, "gemm_bf16_stamps: M=%d N=%d K=%d", M, N, K);
+  UFND_REQUIRE(tile_cfg >= 0 && tile_cfg < kNumTiles && N % kTiles[tile_cfg].bn == 0, "gemm_bf16_stamps: tile config %d", tile_cfg);
+  GemmArgs a{(const __bf16*)A, (const __bf16*)W, nullptr, nullptr, (__bf16*)out_bf16, nullptr, M, N, K, K, K, 0, N, 0, 0, 0, 0, 1, stamps};
+  int rc = launch_cfg(tile_cfg, 3, a, (hipStream_t)stream_);
   if (rc != UFND_OK) return rc;
   UFND_CHECK_LAUNCH();
   return UFND_OK;

@@ -114,6 +114,8 @@ class BertTextEncoder(_EncoderBase):
         self.max_position = max_position
         # output.dense as a 2-way split-K GEMM when the token count gives a full wave of 128x192 tiles
         self.ffn2_split = 2 if (intermediate % 128 == 0 and hidden % 192 == 0) else 1
+        import os
+        self.ffn2_split = int(os.environ.get("UFND_FFN2_SPLIT", self.ffn2_split))   # experiment knob
         w = self._w
         g = torch.Generator().manual_seed(0)
 
