@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1]: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-fold-ln", action="store_true", help="one LayerNorm kernel per LayerNorm instead of folding them into the GEMM epilogues")
     ap.add_argument("--head-only", action="store_true",
                     help="secondary measurement: the reference's actual training mode (cached features, no encoders in the step)")
     args = ap.parse_args()
@@ -143,8 +144,8 @@ def main():
                           "algorithmic_MB_per_step": round(11 * 4 * P / 1e6, 1),
                           "hbm_GBps_algorithmic": round(11 * 4 * P / (dt / args.steps) / 1e9, 1)}))
         return
-    tenc = BertTextEncoder().to(dev)            # BERT-base geometry, random init (no checkpoints offline)
-    venc = ClipVisualEncoder().to(dev)          # CLIP ViT-B/32 geometry, random init
+    tenc = BertTextEncoder(fold_ln=not args.no_fold_ln).to(dev)            # BERT-base geometry, random init (no checkpoints offline)
+    venc = ClipVisualEncoder(fold_ln=not args.no_fold_ln).to(dev)          # CLIP ViT-B/32 geometry, random init
     cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir="/tmp/ufnd_bench", batch_size=B, device=str(dev),
                       use_graph=not args.no_graph, encode_inline=True, seed=42)
     tsync = TemporalSyncNet(in_dim=768, out_dim=256).to(dev)   # temporal = align(text, visual), as the cache builder does

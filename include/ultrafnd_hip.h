@@ -212,6 +212,39 @@ int ufnd_gemm_bf16_ex(const void* A, const void* W, const float* bias, const flo
                       float* out_f32, int M, int N, int K, int lda, int ldw, int ldr, int ldo, int ldf, int act,
                       int tile_cfg, void* stream);
 
+/* LayerNorm-aware form: the LayerNorms around a Linear are folded into the GEMM epilogues, so that no
+ * LayerNorm kernel (and no normalised copy of the activations) sits between two Linears.
+ *   producer side  out_stats (M, N/32, 2): the partial {sum, sum of squares} of every aligned group of 32
+ *                  columns of the fp32 output row (N/32 = ufnd_gemm_bf16_stat_parts(M,N,K), <= 24).
+ *   consumer side  a_stats (M, a_parts, 2) + colsum (N): A is the bf16 rounding of the UN-normalised rows;
+ *                  with W' = W * gamma (rows scaled, rounded to bf16), colsum[n] = sum_k W'[n,k] and
+ *                  bias' = b + W beta:  LayerNorm(x) W^T + b = rstd (x W'^T - mean colsum) + bias'.
+ *   residual side  r_stats (M, r_parts, 2) + r_gamma, r_beta (N): the residual added is
+ *                  LayerNorm(residual) * r_gamma + r_beta (BERT's post-LN stream), computed on the fly.
+ * a_stats and r_stats are mutually exclusive per call; partial counts are even, 2..24; statistics are
+ * over `width` elements; partial layout and summation order are canonical (independent of the tile the
+ * shape selects, no atomics): results are run-to-run identical and a row's outputs do not depend on the
+ * batch it is computed in.
+ * Replaces nn.LayerNorm + nn.Linear pairs of the third-party encoders (transformers modeling_bert.py
+ * BertSelfOutput / BertOutput, modeling_clip.py CLIPEncoderLayer) behind text_blocks.py:79. */
+typedef struct ufnd_gemm_ln {
+  const float* a_stats;
+  const float* colsum;
+  const float* r_stats;
+  const float* r_gamma;
+  const float* r_beta;
+  float* out_stats;
+  int a_parts, r_parts;
+  float a_eps, r_eps;
+  int width;
+} ufnd_gemm_ln;
+int ufnd_gemm_bf16_ln(const void* A, const void* W, const float* bias, const float* residual, void* out_bf16,
+                      float* out_f32, int M, int N, int K, int lda, int ldw, int ldr, int ldo, int ldf, int act,
+                      const ufnd_gemm_ln* ln, void* stream);
+/* Number of {sum, sumsq} partials per row that ufnd_gemm_bf16_ln writes to out_stats for this shape
+ * (0 = the shape's tile has no statistics epilogue). */
+int ufnd_gemm_bf16_stat_parts(int M, int N, int K);
+
 /* Diagnostics: one launch of tile `tile_cfg` (plain bf16 output, no epilogue extras) built with
  * in-kernel clock stamps.  stamps receives 8 uint64 per block: {s_memtime, s_memrealtime} at kernel
  * entry, after the first K-step has landed, after the K loop, after the last store has drained.
@@ -265,9 +298,12 @@ int ufnd_field_mean_l2(const float* parts, const int32_t* valid, float* out, int
  * patches (N*(S/P)^2, 3*P*P) bf16 in the conv weight's (c,ky,kx) order. */
 int ufnd_vit_patchify(const float* frames, void* patches_bf16, int N, int image, int patch, void* stream);
 
-/* tokens = pre_layrnorm([class_embedding ; patch_emb] + position_embedding) -> x_f32 (N, P+1, H). */
+/* tokens = pre_layrnorm([class_embedding ; patch_emb] + position_embedding) -> x_f32 (N, P+1, H);
+ * optionally also the bf16 rounding (x_bf16) and the rows' {sum, sumsq} as two partials per row
+ * (stats (N*(P+1), 2, 2): the a_stats operand of ufnd_gemm_bf16_ln for the first layer). */
 int ufnd_vit_assemble(const float* patch_emb, const float* cls, const float* pos, const float* gamma,
-                      const float* beta, float* x_f32, int N, int P, int H, float eps, void* stream);
+                      const float* beta, float* x_f32, void* x_bf16, float* stats, int N, int P, int H, float eps,
+                      void* stream);
 
 /* per-frame e / (||e|| + 1e-9); then, for F > 1, mean over the F frames of a sample and
  * L2-normalise again (text_blocks.py:126-128 idiom).  e (B*F, D) fp32 -> out (B, D). */

@@ -97,6 +97,116 @@ def test_layernorm(M, H, eps):
     assert (ob.float() - ref).abs().max().item() <= 2 ** -8 * ref.abs().max().item() + 2e-5
 
 
+def _gemm_ln(A, W, bias, M, N, K, act=0, residual=None, a_stats=None, colsum=None, r_stats=None, r_gamma=None, r_beta=None,
+             want_stats=False, eps=1e-5, width=768):
+    L = _lib()
+    ob = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    of = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    parts = L.lib().ufnd_gemm_bf16_stat_parts(M, N, K)
+    st = torch.full((M, max(parts, 1), 2), float("nan"), device=DEV) if want_stats else None
+    ln = L.GemmLn()
+    ln.a_stats, ln.colsum, ln.r_stats, ln.r_gamma, ln.r_beta = L.ptr(a_stats), L.ptr(colsum), L.ptr(r_stats), L.ptr(r_gamma), L.ptr(r_beta)
+    ln.out_stats = L.ptr(st)
+    ln.a_parts = a_stats.shape[1] if a_stats is not None else 0
+    ln.r_parts = r_stats.shape[1] if r_stats is not None else 0
+    ln.a_eps = ln.r_eps = eps
+    ln.width = width
+    L.check(L.lib().ufnd_gemm_bf16_ln(A.data_ptr(), W.data_ptr(), L.ptr(bias), L.ptr(residual), ob.data_ptr(), of.data_ptr(), M, N, K,
+                                      K, K, N if residual is not None else 0, N, N, act, C.byref(ln), L.stream_ptr(A.device)), "gemm_ln")
+    torch.cuda.synchronize()
+    return ob, of, st
+
+
+def _split_stats(x, parts):
+    """(M, H) fp32 -> (M, parts, 2) partial {sum, sumsq} over `parts` equal column slices."""
+    M, H = x.shape
+    xs = x.view(M, parts, H // parts)
+    return torch.stack([xs.sum(-1), (xs * xs).sum(-1)], -1).contiguous()
+
+
+@pytest.mark.parametrize("M,N,K,act,parts", [(4096, 2304, 768, 0, 12), (4096, 3072, 768, 1, 12), (1600, 3072, 768, 2, 24),
+                                             (1600, 2304, 768, 0, 2), (130, 2304, 768, 0, 12)])
+def test_gemm_ln_folds_the_layernorm_of_its_input(M, N, K, act, parts):
+    """LayerNorm(x) W^T + b through ufnd_gemm_bf16_ln (un-normalised bf16 rows + row statistics + W*gamma)
+    against the fp32 torch evaluation; same bounds as the plain GEMM (one more bf16 rounding of x)."""
+    g = torch.Generator().manual_seed(M + N)
+    x = (torch.randn(M, K, generator=g) * 2.0 + 0.3).to(DEV)
+    Wf = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    b, gm, bt = (torch.randn(N, generator=g).to(DEV), (1 + 0.2 * torch.randn(K, generator=g)).to(DEV), (0.1 * torch.randn(K, generator=g)).to(DEV))
+    Wp = (Wf * gm[None, :]).bfloat16()
+    colsum = Wp.float().sum(1).contiguous()
+    bias = (b + Wf @ bt).contiguous()
+    ob, of, _ = _gemm_ln(x.bfloat16(), Wp, bias, M, N, K, act=act, a_stats=_split_stats(x, parts), colsum=colsum, eps=1e-5, width=K)
+    ref = F.layer_norm(x, (K,), gm, bt, 1e-5) @ Wf.t() + b
+    ref = F.gelu(ref) if act == 1 else (ref * torch.sigmoid(1.702 * ref) if act == 2 else ref)
+    scale = max(ref.abs().max().item(), 1.0)
+    e32, e16 = (of - ref).abs().max().item(), (ob.float() - ref).abs().max().item()
+    print(f"gemm_ln fold {M}x{N}x{K} act={act}: f32 err {e32:.2e} bf16 err {e16:.2e} scale {scale:.2f}")
+    assert e32 <= 6e-3 * scale and e16 <= (6e-3 + 2 ** -8) * scale, (e32, e16)
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 768, 768), (4096, 768, 3072), (1600, 768, 3072), (131, 768, 768)])
+def test_gemm_ln_residual_through_layernorm_and_row_statistics(M, N, K):
+    """out = A W^T + b + LayerNorm(r) * gamma + beta, plus the partial row statistics of out."""
+    L = _lib()
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, K, generator=g).to(DEV).bfloat16()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV).bfloat16()
+    b = torch.randn(N, generator=g).to(DEV)
+    r = (torch.randn(M, N, generator=g) * 1.5 - 0.2).to(DEV)
+    gm, bt = (1 + 0.2 * torch.randn(N, generator=g)).to(DEV), (0.1 * torch.randn(N, generator=g)).to(DEV)
+    ob, of, st = _gemm_ln(A, W, b, M, N, K, residual=r, r_stats=_split_stats(r, 12), r_gamma=gm, r_beta=bt, want_stats=True,
+                          eps=1e-12, width=N)
+    ref = A.float() @ W.float().t() + b + F.layer_norm(r, (N,), gm, bt, 1e-12)
+    scale = max(ref.abs().max().item(), 1.0)
+    assert (of - ref).abs().max().item() <= 2e-3 * scale
+    assert (ob.float() - ref).abs().max().item() <= (2e-3 + 2 ** -8) * scale
+    parts = L.lib().ufnd_gemm_bf16_stat_parts(M, N, K)
+    assert parts == N // 32 and st.shape[1] == parts and not torch.isnan(st).any()
+    assert (st - _split_stats(of, parts)).abs().max().item() <= 1e-4 * scale * scale * 32
+    tot = st.sum(1)
+    assert (tot[:, 0] - of.sum(1)).abs().max().item() <= 2e-3 * N ** 0.5 * scale
+    assert ((tot[:, 1] - (of * of).sum(1)).abs() / (of * of).sum(1)).max().item() <= 1e-5
+    # plain residual (no LayerNorm on it) through the same entry point
+    ob2, of2, _ = _gemm_ln(A, W, b, M, N, K, residual=r, eps=1e-12, width=N)
+    assert (of2 - (A.float() @ W.float().t() + b + r)).abs().max().item() <= 2e-3 * scale
+
+
+@pytest.mark.parametrize("which", ["bert", "vit"])
+def test_folded_layernorm_encoders_match_the_unfolded_ones(which):
+    """fold_ln=True (no LayerNorm kernels between Linears) against fold_ln=False (one LayerNorm kernel per
+    LayerNorm), same weights with non-trivial gamma / beta, 3 layers: hidden states agree to bf16 noise."""
+    from ultrafnd_git_amd.encoders import BertTextEncoder, ClipVisualEncoder
+    g = torch.Generator().manual_seed(5)
+    if which == "bert":
+        a, b = BertTextEncoder(layers=3, vocab_size=1000, fold_ln=True), BertTextEncoder(layers=3, vocab_size=1000, fold_ln=False)
+    else:
+        a, b = ClipVisualEncoder(layers=3, fold_ln=True), ClipVisualEncoder(layers=3, fold_ln=False)
+    sd = a.state_dict()
+    for k in sd:
+        if "LayerNorm" in k or "layer_norm" in k or "layrnorm" in k or "layernorm" in k:
+            sd[k] = sd[k] + (0.3 if k.endswith("weight") else 0.2) * torch.randn(sd[k].shape, generator=g)
+        elif k.endswith("bias"):
+            sd[k] = 0.05 * torch.randn(sd[k].shape, generator=g)
+    a.load_state_dict(sd); b.load_state_dict(sd)
+    a, b = a.to(DEV), b.to(DEV)
+    if which == "bert":
+        ids = torch.randint(0, 1000, (5, 128), generator=g)
+        mask = (torch.arange(128)[None, :] < torch.tensor([128, 77, 16, 100, 1])[:, None]).int()
+        ha, hb = a.last_hidden_state(ids, mask).clone(), b.last_hidden_state(ids, mask).clone()
+        fa, fb = a(ids, mask).clone(), b(ids, mask).clone()
+        assert "st1" in a._workbufs(5, 128) and "st1" not in b._workbufs(5, 128)
+    else:
+        fr = torch.randn(3, 2, 3, 224, 224, generator=g)
+        ha, hb = a._run(fr)[0].clone(), b._run(fr)[0].clone()
+        fa, fb = a(fr).clone(), b(fr).clone()
+        assert "st0" in a._workbufs(3, 2) and "st0" not in b._workbufs(3, 2)
+    eh = (ha - hb).abs().max().item() / hb.abs().max().item()
+    ef = (fa - fb).abs().max().item()
+    print(f"{which}: folded vs unfolded hidden rel err {eh:.2e}, feature err {ef:.2e}")
+    assert eh <= 2e-2 and ef <= 2e-3, (eh, ef)
+
+
 @pytest.mark.parametrize("B,Lq,masked", [(3, 128, True), (2, 50, False), (2, 40, True), (2, 512, True), (1, 130, True)])
 def test_attention(B, Lq, masked):
     L = _lib()

@@ -49,6 +49,12 @@ class ClfParams(C.Structure):
                                    "bypass_w", "bypass_b", "temperature")]
 
 
+class GemmLn(C.Structure):
+    """ufnd_gemm_ln: the LayerNorm extras of ufnd_gemm_bf16_ln."""
+    _fields_ = [("a_stats", _FP), ("colsum", _FP), ("r_stats", _FP), ("r_gamma", _FP), ("r_beta", _FP), ("out_stats", _FP),
+                ("a_parts", C.c_int), ("r_parts", C.c_int), ("a_eps", C.c_float), ("r_eps", C.c_float), ("width", C.c_int)]
+
+
 STEP_STATE_BYTES = C.sizeof(StepState)
 
 _lib: Optional[C.CDLL] = None
@@ -95,7 +101,9 @@ def _declare_encoders(lib: C.CDLL) -> None:
         "ufnd_bert_embed": [P] * 8 + [I, I, I, I, F, P],
         "ufnd_masked_meanpool_l2": [P, P, P, I, I, I, P],
         "ufnd_vit_patchify": [P, P, I, I, I, P],
-        "ufnd_vit_assemble": [P] * 6 + [I, I, I, F, P],
+        "ufnd_vit_assemble": [P] * 8 + [I, I, I, F, P],
+        "ufnd_gemm_bf16_ln": [P] * 6 + [I] * 9 + [C.POINTER(GemmLn), P],
+        "ufnd_gemm_bf16_stat_parts": [I, I, I],
         "ufnd_l2norm_frames": [P, P, I, I, I, P],
         "ufnd_field_mean_l2": [P, P, P, I, I, I, P],
         "ufnd_temporal_align": [P] * 8 + [I] * 5 + [P],

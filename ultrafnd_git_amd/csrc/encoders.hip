@@ -45,6 +45,20 @@ __device__ __forceinline__ void store_row(const f32x4 (&v)[NI], __bf16* ob, floa
   }
 }
 
+// {sum, sum of squares} of the row held in v[] -> stats[row] as TWO partials ({s, q}, {0, 0}): the
+// layout ufnd_gemm_bf16_ln reads its a_stats in (even partial counts)
+template <int NI>
+__device__ __forceinline__ void row_stats(const f32x4 (&v)[NI], float* stats, size_t row, int lane) {
+  float s = 0.0f, q = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s += v[i][k]; q += v[i][k] * v[i][k]; }
+  s = wave_sum(s);
+  q = wave_sum(q);
+  if (lane == 0) *reinterpret_cast<f32x4*>(stats + row * 4) = f32x4{s, q, 0.0f, 0.0f};
+}
+
 template <int NI>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, int ldx, const float* gamma, const float* beta,
                                                         __bf16* ob, float* of, int M, int H, float eps) {
@@ -159,8 +173,8 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* frames, __bf
 // x[n][0] = cls + pos[0]; x[n][1+p] = patch_emb[n*P+p] + pos[1+p]; then pre-LayerNorm
 template <int NI>
 __global__ __launch_bounds__(256) void vit_assemble_kernel(const float* pe, const float* cls, const float* pos,
-                                                           const float* gamma, const float* beta, float* of, int M,
-                                                           int P, int H, float eps) {
+                                                           const float* gamma, const float* beta, float* of, __bf16* ob,
+                                                           float* stats, int M, int P, int H, float eps) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -173,7 +187,8 @@ __global__ __launch_bounds__(256) void vit_assemble_kernel(const float* pe, cons
     v[i] = base + ld4(pos + (size_t)t * H + col);
   }
   ln_row<NI>(v, H, eps, gamma, beta, lane);
-  store_row<NI>(v, nullptr, of, row, H, lane);
+  store_row<NI>(v, ob, of, row, H, lane);
+  if (stats) row_stats<NI>(v, stats, row, lane);
 }
 
 // per-frame L2 normalise, mean over frames, L2 normalise again (F > 1); one block per sample
@@ -316,12 +331,14 @@ extern "C" int ufnd_vit_patchify(const float* frames, void* patches, int N, int 
 }
 
 extern "C" int ufnd_vit_assemble(const float* patch_emb, const float* cls, const float* pos, const float* gamma,
-                                 const float* beta, float* x_f32, int N, int P, int H, float eps, void* stream_) {
+                                 const float* beta, float* x_f32, void* x_bf16, float* stats, int N, int P, int H, float eps,
+                                 void* stream_) {
   UFND_REQUIRE(patch_emb && cls && pos && gamma && beta && x_f32 && N >= 1 && P >= 1, "vit_assemble: null argument");
   UFND_REQUIRE(h_ok(H), "vit_assemble: H=%d", H);
   const int M = N * (P + 1);
+  UFND_REQUIRE(!stats || ufnd_aligned(stats, 16), "vit_assemble: stats alignment");
   NI_LAUNCH(H, vit_assemble_kernel, dim3(ufnd_cdiv(M, 4)), (hipStream_t)stream_, patch_emb, cls, pos, gamma, beta, x_f32,
-            M, P, H, eps);
+            (__bf16*)x_bf16, stats, M, P, H, eps);
   UFND_CHECK_LAUNCH();
   return UFND_OK;
 }

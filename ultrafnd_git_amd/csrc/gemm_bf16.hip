@@ -32,6 +32,15 @@ struct GemmArgs {
   int m_tiles, n_tiles;
   int ksplit;            // > 1: block (tile, s) multiplies K-slice s and writes raw fp32 partials to slab s
   unsigned long long* stamps;   // DBG builds only
+  // LayerNorm extras (LNX kernels only; every pointer optional)
+  const float* a_stats;  // (M, a_parts, 2) partial {sum, sumsq} of the fp32 rows A was rounded from: LayerNorm of A folded in
+  const float* colsum;   // (N) sum over k of the bf16 weight row (of W * gamma)
+  const float* r_stats;  // (M, r_parts, 2): the residual is LayerNorm(residual) * r_gamma + r_beta
+  const float* r_gamma;
+  const float* r_beta;
+  float* out_stats;      // (M, N / 32, 2): partial {sum, sumsq} of the fp32 output rows, one per aligned 32 columns
+  int a_parts, r_parts;
+  float a_eps, r_eps, inv_h;   // inv_h = 1 / (row width the statistics are over)
 };
 
 __device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst) {
@@ -64,7 +73,9 @@ template <int V> struct IntC { static constexpr int value = V; };
 // MI = 16: v_mfma_f32_16x16x32_bf16 (one fragment read feeds 32 k of a 16-row tile);
 // MI = 32: v_mfma_f32_32x32x16_bf16 (lane l: row l&31, k = 8(l>>5)+j; half as many matrix
 //          instructions per K-step, so the SIMD's vector issue is held half as long).
-template <int BM, int BN, int WM, int WN, int STA, int STB, int MI, int ABL = 0, int DBG = 0>
+// LNX = 1: the LayerNorm-aware epilogue (row statistics in, folded normalisation, residual through a
+//          LayerNorm, row statistics out) -- see ufnd_gemm_bf16_ln.
+template <int BM, int BN, int WM, int WN, int STA, int STB, int MI, int ABL = 0, int DBG = 0, int LNX = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs a) {
   static_assert(MI == 16 || MI == 32, "MFMA shape");
   using acc_t = typename std::conditional<MI == 16, f32x4, f32x16>::type;
@@ -80,7 +91,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
   constexpr int CP = TN + 4;                     // fp32 C-staging pitch (floats), MI rows per wave
   constexpr int CBYTES = NW * MI * CP * 4;
   constexpr int RING = STA * ASLOT + STB * BSLOT;
-  constexpr int SMEM = (RING > CBYTES) ? RING : CBYTES;
+  constexpr int STAT_OFF = (RING > CBYTES) ? RING : CBYTES;           // LNX: {mean, rstd} per tile row, behind the ring
+  constexpr int SMEM = STAT_OFF + (LNX ? BM * 8 : 0);
   static_assert(SMEM <= 160 * 1024, "LDS budget");
   static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0 && TM % MI == 0 && TN % MI == 0, "tile split");
   static_assert(STB >= 2 && (STA == STB || STA == STB + 1), "ring depths");
@@ -240,7 +252,64 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
   for (; t + STA < nk; ++t) body(t, IntC<1>{}, IntC<1>{}, IntC<1>{});     // steady state
   for (; t + STB < nk; ++t) body(t, IntC<0>{}, IntC<1>{}, IntC<1>{});     // (STA == STB + 1) only W left to fetch
   for (; t + 1 < nk; ++t) body(t, IntC<0>{}, IntC<0>{}, IntC<1>{});       // drain
+  // LNX: the producers' partial {sum, sumsq} of my tile's rows become {mean, rstd} in LDS.  The loads
+  // are issued before the last K-step (no DMA is in flight any more, so they do not disturb the
+  // counted vmcnt) and consumed after it.  The summation order is CANONICAL -- 16-B chunk c (two
+  // partials) belongs to group c % 4, a group adds its chunks in ascending order, the total is
+  // (g0 + g1) + (g2 + g3) -- whatever the tile shape, so a row's statistics (hence its outputs) do
+  // not depend on the batch it is computed in.  No atomics.
+  constexpr int TPR = NW * 64 / BM;                 // threads per tile row: 2 or 4
+  static_assert(!LNX || TPR == 2 || TPR == 4, "threads per tile row");
+  constexpr int GPT = 4 / (TPR < 4 ? TPR : 4);      // groups per thread
+  f32x4 sv[GPT][3];
+  f32x2* st_lds = reinterpret_cast<f32x2*>(smem + STAT_OFF);
+  const float* sp = nullptr;
+  if constexpr (LNX) {
+    sp = a.a_stats ? a.a_stats : a.r_stats;
+    if (sp) {
+      const int parts = a.a_stats ? a.a_parts : a.r_parts;
+      int row = m0 + (int)threadIdx.x / TPR;
+      row = row < a.M ? row : a.M - 1;
+      const f32x4* base = reinterpret_cast<const f32x4*>(sp + (size_t)row * parts * 2);
+      const int nq = parts >> 1, sub = threadIdx.x % TPR;
+#pragma unroll
+      for (int gi = 0; gi < GPT; ++gi)
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const int q = (sub + gi * TPR) + 4 * u;     // chunks of group sub + gi*TPR
+          sv[gi][u] = q < nq ? base[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+  }
   body(t, IntC<0>{}, IntC<0>{}, IntC<0>{});                               // last step: no successor
+  if constexpr (LNX) {
+    if (sp) {
+      float gs[GPT], gq[GPT];
+#pragma unroll
+      for (int gi = 0; gi < GPT; ++gi) {
+        gs[gi] = sv[gi][0][0] + sv[gi][0][2];
+        gq[gi] = sv[gi][0][1] + sv[gi][0][3];
+#pragma unroll
+        for (int u = 1; u < 3; ++u) { gs[gi] += sv[gi][u][0] + sv[gi][u][2]; gq[gi] += sv[gi][u][1] + sv[gi][u][3]; }
+      }
+      float sm, sq;
+      if constexpr (TPR == 4) {        // lane sub holds group sub
+        sm = gs[0] + __shfl_xor(gs[0], 1, 64);
+        sq = gq[0] + __shfl_xor(gq[0], 1, 64);
+        sm += __shfl_xor(sm, 2, 64);
+        sq += __shfl_xor(sq, 2, 64);
+      } else {                         // lane sub holds groups sub and sub + 2
+        const float s01 = gs[0] + __shfl_xor(gs[0], 1, 64), s23 = gs[1] + __shfl_xor(gs[1], 1, 64);
+        const float q01 = gq[0] + __shfl_xor(gq[0], 1, 64), q23 = gq[1] + __shfl_xor(gq[1], 1, 64);
+        sm = s01 + s23;
+        sq = q01 + q23;
+      }
+      const float mean = sm * a.inv_h;
+      const float var = fmaxf(sq * a.inv_h - mean * mean, 0.f);
+      if (threadIdx.x % TPR == 0) st_lds[threadIdx.x / TPR] = f32x2{mean, 1.0f / sqrtf(var + (a.a_stats ? a.a_eps : a.r_eps))};
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();   // everyone is done reading the ring: reuse it for the epilogue
   __builtin_amdgcn_sched_barrier(0);
@@ -271,9 +340,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < AR; ++r) {
-          float v = acc[i][j][r] + bj[j];
-          if constexpr (ACT == UFND_ACT_GELU) v = gelu_fast_f(v);
-          else if constexpr (ACT == UFND_ACT_QUICK_GELU) v = v * sigmoid_fast_f(1.702f * v);
+          float v = acc[i][j][r];
+          if constexpr (!LNX) {     // (LNX: bias and activation follow the folded normalisation, in the row phase)
+            v += bj[j];
+            if constexpr (ACT == UFND_ACT_GELU) v = gelu_fast_f(v);
+            else if constexpr (ACT == UFND_ACT_QUICK_GELU) v = v * sigmoid_fast_f(1.702f * v);
+          }
           // accumulator register r of lane (fr, g): 16x16 -> row 4g + r; 32x32 -> row 8(r>>2) + 4g + (r&3)
           const int prow_ = MI == 16 ? 4 * g + r : 8 * (r >> 2) + 4 * g + (r & 3);
           cst[prow_ * CP + j * MI + fr] = v;
@@ -288,13 +360,68 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         const int col = n0 + wn * TN + cl;
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(cst + rr * CP + cl);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(cst + rr * CP + cl + 4);
-        if (row >= a.M) continue;
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        if (a.residual) {
-          const float* rp = a.residual + (size_t)row * a.ldr + col;
-          const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+        if constexpr (!LNX) {
+          if (row >= a.M) continue;
+          if (a.residual) {
+            const float* rp = a.residual + (size_t)row * a.ldr + col;
+            const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) { v[q] += r0[q]; v[4 + q] += r1[q]; }
+            for (int q = 0; q < 4; ++q) { v[q] += r0[q]; v[4 + q] += r1[q]; }
+          }
+        } else {
+          const bool live = row < a.M;
+          const int rowc = live ? row : a.M - 1;
+          const f32x2 ms = st_lds[rowc - m0];           // {mean, rstd} of this row (a_stats or r_stats)
+          auto ld8 = [&](const float* ptr, float (&o)[8]) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(ptr), x1 = *reinterpret_cast<const f32x4*>(ptr + 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { o[q] = x0[q]; o[4 + q] = x1[q]; }
+          };
+          if (a.a_stats) {        // LayerNorm(A) W'^T = rstd (A W'^T - mean colsum(W'))
+            float cs[8];
+            ld8(a.colsum + col, cs);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = ms[1] * (v[q] - ms[0] * cs[q]);
+          }
+          if (a.bias) {
+            float bb[8];
+            ld8(a.bias + col, bb);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] += bb[q];
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            if constexpr (ACT == UFND_ACT_GELU) v[q] = gelu_fast_f(v[q]);
+            else if constexpr (ACT == UFND_ACT_QUICK_GELU) v[q] = v[q] * sigmoid_fast_f(1.702f * v[q]);
+          }
+          if (a.residual) {
+            float rr8[8];
+            ld8(a.residual + (size_t)rowc * a.ldr + col, rr8);
+            if (a.r_stats) {      // the residual stream is LayerNorm(residual) * gamma + beta, never materialised
+              float gg[8], be[8];
+              ld8(a.r_gamma + col, gg);
+              ld8(a.r_beta + col, be);
+#pragma unroll
+              for (int q = 0; q < 8; ++q) rr8[q] = (rr8[q] - ms[0]) * ms[1] * gg[q] + be[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] += rr8[q];
+          }
+          if (a.out_stats) {      // partial {sum, sumsq} of the fp32 output row over each aligned 32-column group
+            if constexpr (CPR % 4 == 0) {   // (canonical: the partial of columns [32p, 32p+32) never depends on the tile shape)
+              float sm = 0.f, sq = 0.f;
+#pragma unroll
+              for (int q = 0; q < 8; ++q) { sm += v[q]; sq += v[q] * v[q]; }
+              sm += __shfl_xor(sm, 1, 64);
+              sq += __shfl_xor(sq, 1, 64);
+              sm += __shfl_xor(sm, 2, 64);
+              sq += __shfl_xor(sq, 2, 64);
+              if (live && (id & 3) == 0)
+                *reinterpret_cast<f32x2*>(a.out_stats + ((size_t)row * (a.N >> 5) + (col >> 5)) * 2) = f32x2{sm, sq};
+            }
+          }
+          if (!live) continue;
         }
         if (a.out_f32) {
           float* op = a.out_f32 + (size_t)ks * a.M * a.ldf + (size_t)row * a.ldf + col;
@@ -341,60 +468,63 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* src, __bf16
 
 // tile configurations (BM x BN, waves WM x WN, LDS ring slots of A / W).  Exact-fit widths exist
 // because a 256-CU chip wants ~256 (or 512 at 2 blocks/CU) equal tiles per launch, not "as many as
-// it takes".  X(id, BM, BN, WM, WN, STA, STB, MI)
+// it takes".  X(id, BM, BN, WM, WN, STA, STB, MI, LN)  (LN = 1: the LayerNorm-aware kernel exists too)
 #define UFND_GEMM_TILES(X)                                                                             \
-  X(0, 128, 128, 2, 2, 3, 3, 16)   /*  96 KiB */                                                           \
-  X(1, 128, 64, 2, 2, 3, 3, 16)    /*  72 KiB (2 blocks/CU) */                                             \
-  X(2, 256, 128, 4, 2, 3, 3, 16)   /* 144 KiB */                                                           \
-  X(3, 128, 128, 2, 2, 2, 2, 16)   /*  64 KiB (2 blocks/CU) */                                             \
-  X(4, 128, 64, 2, 2, 4, 4, 16)    /*  96 KiB */                                                           \
-  X(5, 256, 64, 4, 2, 3, 3, 16)    /* 120 KiB */                                                           \
-  X(6, 128, 288, 2, 2, 3, 3, 16)   /* 156 KiB (N=2304 -> 8 column tiles) */                                \
-  X(7, 128, 96, 2, 2, 3, 3, 16)    /*  84 KiB (N=768 -> 8 column tiles) */                                 \
-  X(8, 256, 192, 4, 2, 2, 2, 16)   /* 112 KiB (N=3072 -> 16 column tiles) */                               \
-  X(9, 128, 384, 2, 2, 2, 2, 16)   /* 128 KiB */                                                           \
-  X(10, 128, 192, 2, 2, 3, 3, 16)  /* 120 KiB */                                                           \
-  X(11, 128, 96, 2, 2, 4, 4, 16)   /* 112 KiB */                                                           \
-  X(12, 64, 96, 1, 2, 4, 4, 16)    /*  80 KiB (2 blocks/CU; ViT M=1600 -> 25 row tiles) */                 \
-  X(13, 64, 192, 1, 2, 3, 3, 16)   /*  96 KiB */                                                           \
-  X(14, 128, 256, 2, 2, 2, 2, 16)  /*  96 KiB */                                                           \
-  X(15, 256, 256, 4, 2, 2, 2, 16)  /* 128 KiB */                                                           \
-  X(16, 128, 128, 4, 2, 3, 3, 16)  /*  96 KiB (8 waves, wave tile 32x64) */                                \
-  X(17, 128, 192, 4, 2, 3, 3, 16)  /* 120 KiB (8 waves, wave tile 32x96) */                                \
-  X(18, 256, 64, 4, 2, 4, 4, 16)   /* 160 KiB */                                                           \
-  X(19, 64, 64, 1, 2, 4, 4, 16)    /*  64 KiB (2 blocks/CU) */                                             \
-  X(20, 128, 64, 4, 2, 4, 4, 16)   /*  96 KiB (8 waves, wave tile 32x32) */                                \
-  X(21, 256, 192, 2, 4, 2, 2, 16)  /* 112 KiB (wave tile 128x48) */                                        \
-  X(22, 256, 192, 4, 2, 3, 2, 16)  /* 144 KiB: A two K-steps ahead, W one */                               \
-  X(23, 256, 256, 4, 2, 3, 2, 16)  /* 160 KiB */                                                           \
-  X(24, 128, 192, 4, 2, 4, 4, 16)  /* 160 KiB */                                                           \
-  X(25, 128, 256, 4, 2, 3, 3, 16)  /* 144 KiB (8 waves, wave tile 32x128) */                               \
-  X(26, 256, 192, 4, 2, 2, 2, 32)  /* 32x32x16 MFMA forms */                                              \
-  X(27, 256, 192, 4, 2, 3, 2, 32)                                                                      \
-  X(28, 128, 128, 4, 2, 3, 3, 32)                                                                      \
-  X(29, 128, 192, 4, 2, 3, 3, 32)                                                                      \
-  X(30, 256, 256, 4, 2, 3, 2, 32)                                                                      \
-  X(31, 128, 64, 4, 2, 4, 4, 32)                                                                       \
-  X(32, 256, 128, 4, 2, 3, 3, 32)                                                                      \
-  X(33, 128, 64, 2, 2, 3, 3, 32)   /* 2 blocks/CU */
+  X(0, 128, 128, 2, 2, 3, 3, 16, 0)   /*  96 KiB */                                                           \
+  X(1, 128, 64, 2, 2, 3, 3, 16, 0)    /*  72 KiB (2 blocks/CU) */                                             \
+  X(2, 256, 128, 4, 2, 3, 3, 16, 0)   /* 144 KiB */                                                           \
+  X(3, 128, 128, 2, 2, 2, 2, 16, 0)   /*  64 KiB (2 blocks/CU) */                                             \
+  X(4, 128, 64, 2, 2, 4, 4, 16, 0)    /*  96 KiB */                                                           \
+  X(5, 256, 64, 4, 2, 3, 3, 16, 0)    /* 120 KiB */                                                           \
+  X(6, 128, 288, 2, 2, 3, 3, 16, 0)   /* 156 KiB (N=2304 -> 8 column tiles) */                                \
+  X(7, 128, 96, 2, 2, 3, 3, 16, 0)    /*  84 KiB (N=768 -> 8 column tiles) */                                 \
+  X(8, 256, 192, 4, 2, 2, 2, 16, 1)   /* 112 KiB (N=3072 -> 16 column tiles) */                               \
+  X(9, 128, 384, 2, 2, 2, 2, 16, 0)   /* 128 KiB */                                                           \
+  X(10, 128, 192, 2, 2, 3, 3, 16, 0)  /* 120 KiB */                                                           \
+  X(11, 128, 96, 2, 2, 4, 4, 16, 0)   /* 112 KiB */                                                           \
+  X(12, 64, 96, 1, 2, 4, 4, 16, 0)    /*  80 KiB (2 blocks/CU; ViT M=1600 -> 25 row tiles) */                 \
+  X(13, 64, 192, 1, 2, 3, 3, 16, 0)   /*  96 KiB */                                                           \
+  X(14, 128, 256, 2, 2, 2, 2, 16, 0)  /*  96 KiB */                                                           \
+  X(15, 256, 256, 4, 2, 2, 2, 16, 0)  /* 128 KiB */                                                           \
+  X(16, 128, 128, 4, 2, 3, 3, 16, 1)  /*  96 KiB (8 waves, wave tile 32x64) */                                \
+  X(17, 128, 192, 4, 2, 3, 3, 16, 1)  /* 120 KiB (8 waves, wave tile 32x96) */                                \
+  X(18, 256, 64, 4, 2, 4, 4, 16, 0)   /* 160 KiB */                                                           \
+  X(19, 64, 64, 1, 2, 4, 4, 16, 0)    /*  64 KiB (2 blocks/CU) */                                             \
+  X(20, 128, 64, 4, 2, 4, 4, 16, 1)   /*  96 KiB (8 waves, wave tile 32x32) */                                \
+  X(21, 256, 192, 2, 4, 2, 2, 16, 0)  /* 112 KiB (wave tile 128x48) */                                        \
+  X(22, 256, 192, 4, 2, 3, 2, 16, 0)  /* 144 KiB: A two K-steps ahead, W one */                               \
+  X(23, 256, 256, 4, 2, 3, 2, 16, 0)  /* 160 KiB */                                                           \
+  X(24, 128, 192, 4, 2, 4, 4, 16, 0)  /* 160 KiB */                                                           \
+  X(25, 128, 256, 4, 2, 3, 3, 16, 0)  /* 144 KiB (8 waves, wave tile 32x128) */                               \
+  X(26, 256, 192, 4, 2, 2, 2, 32, 0)  /* 32x32x16 MFMA forms */                                              \
+  X(27, 256, 192, 4, 2, 3, 2, 32, 0)                                                                      \
+  X(28, 128, 128, 4, 2, 3, 3, 32, 0)                                                                      \
+  X(29, 128, 192, 4, 2, 3, 3, 32, 0)                                                                      \
+  X(30, 256, 256, 4, 2, 3, 2, 32, 0)                                                                      \
+  X(31, 128, 64, 4, 2, 4, 4, 32, 0)                                                                       \
+  X(32, 256, 128, 4, 2, 3, 3, 32, 0)                                                                      \
+  X(33, 128, 64, 2, 2, 3, 3, 32, 0)   /* 2 blocks/CU */
 
-struct TileCfg { int bm, bn, threads; };
+struct TileCfg { int bm, bn, threads, wn, lnx; };
 static const TileCfg kTiles[] = {
-#define X(id, BM_, BN_, WM_, WN_, SA_, SB_, MI_) {BM_, BN_, WM_ * WN_ * 64},
+#define X(id, BM_, BN_, WM_, WN_, SA_, SB_, MI_, LN_) {BM_, BN_, WM_ * WN_ * 64, WN_, LN_},
     UFND_GEMM_TILES(X)
 #undef X
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
+// abl: 0 product kernel, 1 / 2 timing ablations, 3 stamps build, 4 LayerNorm-aware kernel
 static int launch_cfg(int cfg, int abl, GemmArgs& a, hipStream_t stream) {
   const TileCfg& t = kTiles[cfg];
   a.m_tiles = ufnd_cdiv(a.M, t.bm);
   a.n_tiles = a.N / t.bn;
   const dim3 grid(a.m_tiles * a.n_tiles * a.ksplit), block(t.threads);
-#define X(id, BM_, BN_, WM_, WN_, SA_, SB_, MI_)                                                                   \
+#define X(id, BM_, BN_, WM_, WN_, SA_, SB_, MI_, LN_)                                                              \
   case id:                                                                                                          \
     if constexpr (SA_ * BM_ * 128 + SB_ * BN_ * 128 <= 160 * 1024) {                                                \
-      if (abl == 0) hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, SA_, SB_, MI_, 0, 0>), grid, block, 0, stream, a);      \
+      if (abl == 4) {                                                                                               \
+        if constexpr (LN_ != 0) hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, SA_, SB_, MI_, 0, 0, 1>), grid, block, 0, stream, a); \
+      } else if (abl == 0) hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, SA_, SB_, MI_, 0, 0>), grid, block, 0, stream, a);      \
       else if (abl == 1) hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, SA_, SB_, MI_, 1, 0>), grid, block, 0, stream, a); \
       else if (abl == 2) hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, SA_, SB_, MI_, 2, 0>), grid, block, 0, stream, a); \
       else hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, SA_, SB_, MI_, 0, 1>), grid, block, 0, stream, a);   \
@@ -413,6 +543,8 @@ static int launch_cfg(int cfg, int abl, GemmArgs& a, hipStream_t stream) {
 // many, because L2->LDS traffic falls as 1/BM + 1/BN; 8-wave workgroups throughout (two waves per
 // SIMD keep the matrix pipe fed across the mid-step barrier).
 static int auto_cfg(int M, int N, int K) {
+  static const int forced = [] { const char* e = getenv("UFND_GEMM_FORCE_CFG"); return e ? atoi(e) : -1; }();   // experiments only
+  if (forced >= 0 && forced < kNumTiles && N % kTiles[forced].bn == 0) return forced;
   auto tiles = [&](int cfg) { return (long long)ufnd_cdiv(M, kTiles[cfg].bm) * (N / kTiles[cfg].bn); };
   if (N % 192 == 0 && tiles(8) >= 160) return 8;      // 256x192: BERT QKV (192 tiles) / FFN1 (256)
   if (N >= 2048) {                                     // wide N, fewer rows (ViT QKV / FFN1): 32-row wave tiles
@@ -459,6 +591,52 @@ extern "C" int ufnd_gemm_bf16_splitk(const void* A, const void* W, float* slabs,
   if (N % kTiles[cfg < kNumTiles ? cfg : 0].bn != 0) cfg = 1;
   UFND_REQUIRE(cfg < kNumTiles && N % kTiles[cfg].bn == 0, "gemm_bf16_splitk: tile config %d does not divide N=%d", cfg, N);
   int rc = launch_cfg(cfg, 0, a, (hipStream_t)stream_);
+  if (rc != UFND_OK) return rc;
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}
+
+extern "C" int ufnd_gemm_bf16_stat_parts(int M, int N, int K) {
+  const int cfg = auto_cfg(M, N, K);
+  const TileCfg& t = kTiles[cfg];
+  const int tn = t.bn / t.wn;
+  if (!t.lnx || N % t.bn != 0 || tn % 32 != 0 || (N / 32) % 2 != 0 || N / 32 > 24) return 0;
+  return N / 32;
+}
+
+extern "C" int ufnd_gemm_bf16_ln(const void* A, const void* W, const float* bias, const float* residual, void* out_bf16,
+                                 float* out_f32, int M, int N, int K, int lda, int ldw, int ldr, int ldo, int ldf, int act,
+                                 const ufnd_gemm_ln* ln, void* stream_) {
+  UFND_REQUIRE(A && W && ln && (out_bf16 || out_f32), "gemm_bf16_ln: null operand");
+  UFND_REQUIRE(M >= 1 && N >= 64 && K >= 64 && N % 64 == 0 && K % 64 == 0, "gemm_bf16_ln: M=%d N=%d K=%d (need N%%64==0, K%%64==0)", M, N, K);
+  UFND_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K && ufnd_aligned(A, 16) && ufnd_aligned(W, 16),
+               "gemm_bf16_ln: A/W strides must be multiples of 8 and pointers 16-B aligned");
+  UFND_REQUIRE(!residual || (ldr % 4 == 0 && ldr >= N && ufnd_aligned(residual, 16)), "gemm_bf16_ln: residual alignment");
+  UFND_REQUIRE(!out_f32 || (ldf % 4 == 0 && ldf >= N && ufnd_aligned(out_f32, 16)), "gemm_bf16_ln: out_f32 alignment");
+  UFND_REQUIRE(!out_bf16 || (ldo % 8 == 0 && ldo >= N && ufnd_aligned(out_bf16, 16)), "gemm_bf16_ln: out_bf16 alignment");
+  UFND_REQUIRE(!bias || ufnd_aligned(bias, 16), "gemm_bf16_ln: bias must be 16-B aligned");
+  UFND_REQUIRE(act >= 0 && act <= 2, "gemm_bf16_ln: act=%d", act);
+  UFND_REQUIRE(!(ln->a_stats && ln->r_stats), "gemm_bf16_ln: a_stats and r_stats are mutually exclusive");
+  UFND_REQUIRE(ln->width > 0, "gemm_bf16_ln: width (the LayerNorm dimension) must be positive");
+  if (ln->a_stats) {
+    UFND_REQUIRE(ln->colsum && ufnd_aligned(ln->colsum, 16) && ufnd_aligned(ln->a_stats, 16), "gemm_bf16_ln: colsum / a_stats alignment");
+    UFND_REQUIRE(ln->a_parts >= 2 && ln->a_parts <= 24 && ln->a_parts % 2 == 0, "gemm_bf16_ln: a_parts=%d (even, 2..24)", ln->a_parts);
+  }
+  if (ln->r_stats) {
+    UFND_REQUIRE(residual && ln->r_gamma && ln->r_beta && ufnd_aligned(ln->r_gamma, 16) && ufnd_aligned(ln->r_beta, 16) &&
+                     ufnd_aligned(ln->r_stats, 16), "gemm_bf16_ln: r_stats needs residual, r_gamma, r_beta (16-B aligned)");
+    UFND_REQUIRE(ln->r_parts >= 2 && ln->r_parts <= 24 && ln->r_parts % 2 == 0, "gemm_bf16_ln: r_parts=%d (even, 2..24)", ln->r_parts);
+  }
+  const int cfg = auto_cfg(M, N, K);
+  UFND_REQUIRE(kTiles[cfg].lnx && N % kTiles[cfg].bn == 0, "gemm_bf16_ln: no LayerNorm-aware kernel for M=%d N=%d K=%d", M, N, K);
+  if (ln->out_stats) {
+    UFND_REQUIRE(ufnd_gemm_bf16_stat_parts(M, N, K) > 0 && ufnd_aligned(ln->out_stats, 16), "gemm_bf16_ln: out_stats unsupported for this shape");
+  }
+  GemmArgs a{(const __bf16*)A, (const __bf16*)W, bias, residual, (__bf16*)out_bf16, out_f32, M, N, K, lda, ldw, ldr, ldo, ldf, act, 0, 0, 1, nullptr};
+  a.a_stats = ln->a_stats; a.colsum = ln->colsum; a.r_stats = ln->r_stats; a.r_gamma = ln->r_gamma; a.r_beta = ln->r_beta;
+  a.out_stats = ln->out_stats; a.a_parts = ln->a_parts; a.r_parts = ln->r_parts; a.a_eps = ln->a_eps; a.r_eps = ln->r_eps;
+  a.inv_h = 1.0f / (float)ln->width;
+  int rc = launch_cfg(cfg, 4, a, (hipStream_t)stream_);
   if (rc != UFND_OK) return rc;
   UFND_CHECK_LAUNCH();
   return UFND_OK;

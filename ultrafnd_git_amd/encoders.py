@@ -15,6 +15,13 @@ Weights keep the third-party `state_dict` names so real checkpoints load unchang
 masters are converted once to bf16 MFMA operands (Q/K/V stacked into one (3H,H) matrix).
 Every Linear is `ufnd_gemm_bf16` with fused bias / GELU / residual epilogues; the residual
 stream and all LayerNorm / softmax statistics stay fp32.  No CPU path.
+
+LayerNorm folding (`fold_ln=True`, the default): no LayerNorm kernel runs between two Linears.
+The GEMM that produces a residual-stream row also writes its bf16 rounding and partial
+{sum, sum of squares}; the Linear that consumes LayerNorm(row) multiplies the UN-normalised bf16
+row by W * gamma and applies  rstd (acc - mean colsum) + (b + W beta)  in its epilogue
+(`ufnd_gemm_bf16_ln`); BERT's post-LN residual LayerNorm(row) * gamma + beta is evaluated on the fly
+in the epilogue of the GEMM that adds it.  `fold_ln=False` keeps one LayerNorm kernel per LayerNorm.
 """
 from __future__ import annotations
 
@@ -94,6 +101,34 @@ class _EncoderBase(nn.Module):
                                        out_f32.stride(0) if out_f32 is not None else 0, act,
                                        L.stream_ptr(A.device)), "ufnd_gemm_bf16")
 
+    def _gemm_ln(self, A, W, bias, out_bf16=None, out_f32=None, residual=None, act=ACT_NONE, a_stats=None, colsum=None,
+                 r_stats=None, r_gamma=None, r_beta=None, out_stats=None, eps=1e-5):
+        """ufnd_gemm_bf16_ln: a_stats / r_stats / out_stats are (M, parts, 2) fp32 tensors."""
+        M = A.shape[0]
+        N, K = W.shape
+        ln = L.GemmLn()
+        ln.a_stats, ln.colsum = L.ptr(a_stats), L.ptr(colsum)
+        ln.r_stats, ln.r_gamma, ln.r_beta = L.ptr(r_stats), L.ptr(r_gamma), L.ptr(r_beta)
+        ln.out_stats = L.ptr(out_stats)
+        ln.a_parts = a_stats.shape[1] if a_stats is not None else 0
+        ln.r_parts = r_stats.shape[1] if r_stats is not None else 0
+        ln.a_eps = ln.r_eps = eps
+        ln.width = self.hidden
+        import ctypes
+        L.check(L.lib().ufnd_gemm_bf16_ln(A.data_ptr(), W.data_ptr(), L.ptr(bias), L.ptr(residual), L.ptr(out_bf16),
+                                          L.ptr(out_f32), M, N, K, A.stride(0), W.stride(0),
+                                          residual.stride(0) if residual is not None else 0,
+                                          out_bf16.stride(0) if out_bf16 is not None else 0,
+                                          out_f32.stride(0) if out_f32 is not None else 0, act, ctypes.byref(ln),
+                                          L.stream_ptr(A.device)), "ufnd_gemm_bf16_ln")
+
+    @staticmethod
+    def _fold(W, b, gamma, beta):
+        """LayerNorm(x; gamma, beta) W^T + b  ==  rstd (x W'^T - mean colsum) + b'  with
+        W' = bf16(W * gamma), colsum = row sums of the ROUNDED W', b' = b + W beta."""
+        Wp = _bf16(W * gamma[None, :])
+        return Wp, Wp.float().sum(1).contiguous(), (b + W @ beta).contiguous()
+
     def _ln(self, x, ldx, gamma, beta, out_bf16, out_f32, M, H, eps):
         L.check(L.lib().ufnd_layernorm(x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), L.ptr(out_bf16),
                                        L.ptr(out_f32), M, H, eps, L.stream_ptr(x.device)), "ufnd_layernorm")
@@ -106,16 +141,16 @@ class _EncoderBase(nn.Module):
 # =============================================================================================
 class BertTextEncoder(_EncoderBase):
     def __init__(self, layers: int = 12, hidden: int = 768, heads: int = 12, intermediate: int = 3072,
-                 vocab_size: int = 30522, max_position: int = 512, type_vocab: int = 2, eps: float = 1e-12):
+                 vocab_size: int = 30522, max_position: int = 512, type_vocab: int = 2, eps: float = 1e-12,
+                 fold_ln: bool = True):
         super().__init__()
+        self.fold_ln = fold_ln
         if hidden != heads * 64:
             raise ValueError("head_dim must be 64 (hidden == heads * 64)")
         self.layers, self.hidden, self.heads, self.inter, self.vocab, self.eps = layers, hidden, heads, intermediate, vocab_size, eps
         self.max_position = max_position
         # output.dense as a 2-way split-K GEMM when the token count gives a full wave of 128x192 tiles
-        self.ffn2_split = 2 if (intermediate % 128 == 0 and hidden % 192 == 0) else 1
-        import os
-        self.ffn2_split = int(os.environ.get("UFND_FFN2_SPLIT", self.ffn2_split))   # experiment knob
+        self.ffn2_split = 1      # (a 2-way split-K + slab-summing LayerNorm lost to the direct 128x128 GEMM)
         w = self._w
         g = torch.Generator().manual_seed(0)
 
@@ -155,6 +190,13 @@ class BertTextEncoder(_EncoderBase):
                     "w1": _bf16(w[P + "intermediate.dense.weight"]), "bi": w[P + "intermediate.dense.bias"],
                     "w2": _bf16(w[P + "output.dense.weight"]), "b2": w[P + "output.dense.bias"],
                     "g2": w[P + "output.LayerNorm.weight"], "b2n": w[P + "output.LayerNorm.bias"]})
+                ly = layers[-1]
+                # folded forms: intermediate.dense consumes LayerNorm_1; the NEXT layer's Q/K/V consume LayerNorm_2
+                ly["w1f"], ly["cs1"], ly["bif"] = self._fold(w[P + "intermediate.dense.weight"], ly["bi"], ly["g1"], ly["b1"])
+                if i > 0:
+                    prev = layers[-2]
+                    wq = torch.cat([w[P + f"attention.self.{n}.weight"] for n in ("query", "key", "value")], 0)
+                    ly["wqkvf"], ly["csqkv"], ly["bqkvf"] = self._fold(wq, ly["bqkv"], prev["g2"], prev["b2n"])
             self._packed = {"layers": layers}
         return self._packed
 
@@ -168,6 +210,11 @@ class BertTextEncoder(_EncoderBase):
                                "x1b": torch.empty(M, H, **bf), "x1f": torch.empty(M, H, **f32),
                                "qkv": torch.empty(M, 3 * H, **bf), "ctx": torch.empty(M, H, **bf),
                                "h": torch.empty(M, self.inter, **bf), "feat": torch.empty(B, H, **f32)}
+            p1 = L.lib().ufnd_gemm_bf16_stat_parts(M, H, H)
+            p2 = L.lib().ufnd_gemm_bf16_stat_parts(M, H, self.inter)
+            if self.fold_ln and p1 > 0 and p2 > 0 and p1 % 2 == 0 and p2 % 2 == 0:
+                self._bufs[key].update({"y2": torch.empty(M, H, **f32), "y1b": torch.empty(M, H, **bf), "y2b": torch.empty(M, H, **bf),
+                                        "st1": torch.zeros(M, p1, 2, **f32), "st2": torch.zeros(M, p2, 2, **f32)})
         return self._bufs[key]
 
     @torch.no_grad()
@@ -190,6 +237,8 @@ class BertTextEncoder(_EncoderBase):
                                         w["embeddings.LayerNorm.weight"].data_ptr(), w["embeddings.LayerNorm.bias"].data_ptr(),
                                         b["xb"].data_ptr(), b["xf"].data_ptr(), B, Lq, H, self.vocab, self.eps,
                                         L.stream_ptr(dev)), "ufnd_bert_embed")
+        if "st1" in b:
+            return self._layers_folded(p, b, mask, B, Lq)
         for ly in p["layers"]:
             self._gemm(b["xb"], ly["wqkv"], ly["bqkv"], out_bf16=b["qkv"])
             self._attn(b["qkv"], mask, b["ctx"], B, Lq, self.heads)
@@ -205,6 +254,30 @@ class BertTextEncoder(_EncoderBase):
             else:
                 self._gemm(b["h"], ly["w2"], ly["b2"], out_f32=b["y"], residual=b["x1f"])
                 self._ln(b["y"], H, ly["g2"], ly["b2n"], b["xb"], b["xf"], M, H, self.eps)
+        return b["xf"].view(B, Lq, H)
+
+    def _layers_folded(self, p, b, mask, B, Lq):
+        """The 12 layers without a LayerNorm kernel between Linears (module docstring).  y1 / y2 are the
+        PRE-LayerNorm sums of the attention and the feed-forward halves (fp32 + bf16 + row statistics)."""
+        M, H, eps = B * Lq, self.hidden, self.eps
+        y1, y2 = b["y"], b["y2"]
+        prev = None
+        for ly in p["layers"]:
+            if prev is None:      # layer 0 consumes the embeddings' own (materialised) LayerNorm
+                self._gemm(b["xb"], ly["wqkv"], ly["bqkv"], out_bf16=b["qkv"])
+            else:
+                self._gemm_ln(b["y2b"], ly["wqkvf"], ly["bqkvf"], out_bf16=b["qkv"], a_stats=b["st2"], colsum=ly["csqkv"], eps=eps)
+            self._attn(b["qkv"], mask, b["ctx"], B, Lq, self.heads)
+            if prev is None:
+                self._gemm_ln(b["ctx"], ly["wo"], ly["bo"], out_f32=y1, out_bf16=b["y1b"], residual=b["xf"], out_stats=b["st1"], eps=eps)
+            else:
+                self._gemm_ln(b["ctx"], ly["wo"], ly["bo"], out_f32=y1, out_bf16=b["y1b"], residual=y2, r_stats=b["st2"],
+                              r_gamma=prev["g2"], r_beta=prev["b2n"], out_stats=b["st1"], eps=eps)
+            self._gemm_ln(b["y1b"], ly["w1f"], ly["bif"], out_bf16=b["h"], act=ACT_GELU, a_stats=b["st1"], colsum=ly["cs1"], eps=eps)
+            self._gemm_ln(b["h"], ly["w2"], ly["b2"], out_f32=y2, out_bf16=b["y2b"], residual=y1, r_stats=b["st1"],
+                          r_gamma=ly["g1"], r_beta=ly["b1"], out_stats=b["st2"], eps=eps)
+            prev = ly
+        self._ln(y2, H, prev["g2"], prev["b2n"], b["xb"], b["xf"], M, H, eps)      # last_hidden_state is materialised once
         return b["xf"].view(B, Lq, H)
 
     @torch.no_grad()
@@ -248,8 +321,9 @@ class BertTextEncoder(_EncoderBase):
 # =============================================================================================
 class ClipVisualEncoder(_EncoderBase):
     def __init__(self, layers: int = 12, hidden: int = 768, heads: int = 12, intermediate: int = 3072, patch: int = 32,
-                 image: int = 224, projection_dim: int = 512, eps: float = 1e-5):
+                 image: int = 224, projection_dim: int = 512, eps: float = 1e-5, fold_ln: bool = True):
         super().__init__()
+        self.fold_ln = fold_ln
         if hidden != heads * 64:
             raise ValueError("head_dim must be 64 (hidden == heads * 64)")
         self.layers, self.hidden, self.heads, self.inter = layers, hidden, heads, intermediate
@@ -289,6 +363,10 @@ class ClipVisualEncoder(_EncoderBase):
                     "w1": _bf16(w[P + "mlp.fc1.weight"]), "bi": w[P + "mlp.fc1.bias"],
                     "w2": _bf16(w[P + "mlp.fc2.weight"]), "b2": w[P + "mlp.fc2.bias"],
                     "g2": w[P + "layer_norm2.weight"], "b2n": w[P + "layer_norm2.bias"]})
+                ly = layers[-1]
+                wq = torch.cat([w[P + f"self_attn.{n}.weight"] for n in ("q_proj", "k_proj", "v_proj")], 0)
+                ly["wqkvf"], ly["csqkv"], ly["bqkvf"] = self._fold(wq, ly["bqkv"], ly["g1"], ly["b1"])
+                ly["w1f"], ly["cs1"], ly["bif"] = self._fold(w[P + "mlp.fc1.weight"], ly["bi"], ly["g2"], ly["b2n"])
             self._packed = {"layers": layers,
                             "wpatch": _bf16(w[V + "embeddings.patch_embedding.weight"].reshape(self.hidden, -1)),
                             "wproj": _bf16(w["visual_projection.weight"])}
@@ -307,6 +385,11 @@ class ClipVisualEncoder(_EncoderBase):
                                "ctx": torch.empty(M, H, **bf), "m": torch.empty(M, self.inter, **bf),
                                "pooled": torch.empty(N, H, **bf), "e": torch.empty(N, self.proj, **f32),
                                "feat": torch.empty(B, self.proj, **f32)}
+            p1 = L.lib().ufnd_gemm_bf16_stat_parts(M, H, H)
+            p2 = L.lib().ufnd_gemm_bf16_stat_parts(M, H, self.inter)
+            if self.fold_ln and p1 > 0 and p2 > 0 and p1 % 2 == 0 and p2 % 2 == 0:
+                self._bufs[key].update({"st0": torch.zeros(M, 2, 2, **f32), "st1": torch.zeros(M, p1, 2, **f32),
+                                        "st2": torch.zeros(M, p2, 2, **f32)})
         return self._bufs[key]
 
     @torch.no_grad()
@@ -331,7 +414,22 @@ class ClipVisualEncoder(_EncoderBase):
         L.check(L.lib().ufnd_vit_assemble(b["pe"].data_ptr(), w[V + "embeddings.class_embedding"].data_ptr(),
                                           w[V + "embeddings.position_embedding.weight"].data_ptr(),
                                           w[V + "pre_layrnorm.weight"].data_ptr(), w[V + "pre_layrnorm.bias"].data_ptr(),
-                                          b["xf"].data_ptr(), N, self.n_patches, H, self.eps, s), "ufnd_vit_assemble")
+                                          b["xf"].data_ptr(), L.ptr(b["hb"]) if "st0" in b else None, L.ptr(b.get("st0")),
+                                          N, self.n_patches, H, self.eps, s), "ufnd_vit_assemble")
+        if "st0" in b:
+            # pre-LN blocks without LayerNorm kernels: hb is the bf16 rounding of the residual stream xf,
+            # st* the row statistics its LayerNorms need (module docstring)
+            eps, stA = self.eps, b["st0"]
+            for ly in p["layers"]:
+                self._gemm_ln(b["hb"], ly["wqkvf"], ly["bqkvf"], out_bf16=b["qkv"], a_stats=stA, colsum=ly["csqkv"], eps=eps)
+                self._attn(b["qkv"], None, b["ctx"], N, T, self.heads)
+                self._gemm_ln(b["ctx"], ly["wo"], ly["bo"], out_f32=b["xf"], out_bf16=b["hb"], residual=b["xf"], out_stats=b["st1"], eps=eps)
+                self._gemm_ln(b["hb"], ly["w1f"], ly["bif"], out_bf16=b["m"], act=ACT_QUICK_GELU, a_stats=b["st1"], colsum=ly["cs1"], eps=eps)
+                self._gemm_ln(b["m"], ly["w2"], ly["b2"], out_f32=b["xf"], out_bf16=b["hb"], residual=b["xf"], out_stats=b["st2"], eps=eps)
+                stA = b["st2"]
+            self._ln(b["xf"], T * H, w[V + "post_layernorm.weight"], w[V + "post_layernorm.bias"], b["pooled"], None, N, H, self.eps)
+            self._gemm(b["pooled"], p["wproj"], None, out_f32=b["e"])
+            return b["e"], b
         for ly in p["layers"]:
             self._ln(b["xf"], H, ly["g1"], ly["b1"], b["hb"], None, M, H, self.eps)
             self._gemm(b["hb"], ly["wqkv"], ly["bqkv"], out_bf16=b["qkv"])

@@ -344,7 +344,10 @@ class ForensicTrainer:
                 "text_out": torch.empty(B, 768, dtype=torch.float32, device=dev),
                 "vis_out": torch.empty(B, 512, dtype=torch.float32, device=dev), "g_text": None, "g_vis": None}
         if self._enc_streams is None:
-            self._enc_streams = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
+            # the text encoder is the long pole of the step (its stream never idles): it gets the high-priority
+            # queue, the visual encoder and the head fill the CUs it leaves free
+            pt, pv = (int(x) for x in os.environ.get("UFND_ENC_PRIO", "-1,0").split(","))
+            self._enc_streams = (torch.cuda.Stream(device=self.device, priority=pt), torch.cuda.Stream(device=self.device, priority=pv))
         return self._enc_bufs[key]
 
     def _encode_text(self, e: dict) -> None:
@@ -391,22 +394,34 @@ class ForensicTrainer:
             if self._slot_free[slot] is not None:
                 strm.wait_event(self._slot_free[slot])   # the head that last used this slot is done with it
         with torch.cuda.stream(st):
+            self._mark("text0", st)
             e["ids"].copy_(ids)
             e["mask"].copy_(batch["attention_mask"])
             self._replay_or_capture(e, "g_text", self._encode_text)
             b["text"].copy_(e["text_out"])
             ev_t = torch.cuda.Event()
             ev_t.record(st)
+            self._mark("text1", st)
         with torch.cuda.stream(sv):
+            self._mark("vis0", sv)
             e["frames"].copy_(frames)
             self._replay_or_capture(e, "g_vis", self._encode_vis)
             b["visual"].copy_(e["vis_out"])
             ev_v = torch.cuda.Event()
             ev_v.record(sv)
+            self._mark("vis1", sv)
         for t in (ids, batch["attention_mask"], frames):
             t.record_stream(st)
             t.record_stream(sv)
         self._feat_ready[slot] = (ev_t, ev_v)
+
+    _timeline: Optional[list] = None     # tools/step_timeline.py sets a list: (tag, timing event) pairs are appended
+
+    def _mark(self, tag: str, stream) -> None:
+        if self._timeline is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(stream)
+            self._timeline.append((tag, ev))
 
     def train_step_pipelined(self, batch: Dict[str, torch.Tensor], next_batch: Optional[Dict[str, torch.Tensor]]) -> dict:
         """train_step for raw batches whose features were started by prefetch_features():
@@ -422,9 +437,11 @@ class ForensicTrainer:
             raise RuntimeError("train_step_pipelined: call prefetch_features(batch) for the first batch")
         inputs_ready = torch.cuda.Event()
         inputs_ready.record(main)                  # next_batch (if any) exists on the device by now
+        self._mark("step0", main)
         for ev in self._feat_ready[slot]:
             main.wait_event(ev)
         self._feat_ready[slot] = None
+        self._mark("head0", main)
         for k_src, k_dst in (("audio_features", "audio"), ("aux", "aux"), ("label", "label"), ("gnn_feat", "gnn")):
             b[k_dst].copy_(batch[k_src])
         if self.temporal_net is not None:      # fakesv_dataset.py:176: U = tsync.align(T, V)
@@ -435,11 +452,13 @@ class ForensicTrainer:
         done = torch.cuda.Event()
         done.record(main)
         self._slot_free[slot] = done
+        self._mark("head1", main)
         self.reducer.start()
         if next_batch is not None:
             self.prefetch_features(next_batch, slot ^ 1, inputs_ready)
         self.reducer.finish()
         self.optim.clip_and_step()
+        self._mark("opt1", main)
         self._slot ^= 1
         return {"loss": self.optim.state.float_view("loss"), "probs": b["probs"], "y": b["label"],
                 "forensic": b["forensic"], "logits": b["logits"]}
@@ -451,17 +470,18 @@ class ForensicTrainer:
         shapes: List[Tuple[int, int, int]] = []
         originals = []
         for enc in (self.text_encoder, self.visual_encoder):
-            orig = enc._gemm
+            for name in ("_gemm", "_gemm_ln"):       # the plain and the LayerNorm-aware entry: the same kernel family
+                orig = getattr(enc, name)
 
-            def timed(A, W, *a, _orig=orig, **kw):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                _orig(A, W, *a, **kw)
-                e1.record()
-                events.append((e0, e1))
-                shapes.append((int(A.shape[0]), int(W.shape[0]), int(W.shape[1])))
-            originals.append((enc, orig))
-            enc._gemm = timed
+                def timed(A, W, *a, _orig=orig, **kw):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    _orig(A, W, *a, **kw)
+                    e1.record()
+                    events.append((e0, e1))
+                    shapes.append((int(A.shape[0]), int(W.shape[0]), int(W.shape[1])))
+                originals.append((enc, name, orig))
+                setattr(enc, name, timed)
         try:
             for _ in range(steps):
                 # park the GPU behind a ~4 ms spin so the host has every launch and event of the pass queued
@@ -472,8 +492,8 @@ class ForensicTrainer:
                 self.visual_encoder(batch["frames"])
             torch.cuda.synchronize(self.device)
         finally:
-            for enc, orig in originals:
-                enc._gemm = orig
+            for enc, name, orig in originals:
+                setattr(enc, name, orig)
         # an event pair around nothing still reads a few us: calibrate it and take it off each launch
         pairs = []
         for _ in range(64):
