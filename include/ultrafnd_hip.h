@@ -322,6 +322,43 @@ int ufnd_temporal_align(const float* text, const float* visual, const float* w0,
                         const float* b3, float* workspace, float* out, int B, int in_dim, int vis_dim, int hidden,
                         int out_dim, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Graph side of the trainer's construction: src/training/forensic_trainer.py
+ *   build_adj_from_ocr :114-132, SimpleGCN :25-53, ForensicTrainer._pretrain_gnn :214-224.
+ * Init-time work in the reference (an O(N^2) Python loop and dense (N,N) products on the CPU).
+ * ---------------------------------------------------------------------------------- */
+
+/* adj (N, N) row stride ld: 1 where i == j or Jaccard(set_i, set_j) >= thresh, else 0 (both sets empty ->
+ * Jaccard 0).  Phrase sets as CSR: offsets (N+1) int32, tokens = every set's phrase ids, sorted ascending and
+ * duplicate-free (any injective phrase -> id map; Jaccard only tests equality).  The comparison is
+ * inter / (union + 1e-9) >= thresh in double, as the reference's Python floats do. */
+int ufnd_ocr_adjacency(const int32_t* offsets, const int32_t* tokens, int N, double thresh, float* adj, int ld, void* stream);
+
+typedef struct ufnd_gcn_params {
+  const float* w1; /* lin1.weight (hid, in_dim) */
+  const float* b1; /* lin1.bias   (hid)         */
+  const float* w2; /* lin2.weight (out, hid)    */
+  const float* b2; /* lin2.bias   (out)         */
+} ufnd_gcn_params;
+
+size_t ufnd_gcn_workspace_floats(int N, int in_dim, int hid, int out_dim, int train);
+
+/* SimpleGCN.forward: z = lin2(A_norm @ dropout(gelu(lin1(A_norm @ x)))), A_norm = D^-1/2 (adj + I) D^-1/2 with
+ * D = rowsum(adj + I) + 1e-9.  x (N, in_dim), adj (N, N) row stride ld_adj, z (N, out_dim).  dropout_p > 0 =
+ * train mode (counter-based mask keyed by state->seed / state->step); in_dim % 4 == 0, hid and out_dim % 32 == 0. */
+int ufnd_gcn_forward(const float* x, const float* adj, int ld_adj, const ufnd_gcn_params* p, float* z, float* workspace, int N,
+                     int in_dim, int hid, int out_dim, float dropout_p, const ufnd_step_state* state, void* stream);
+
+/* One step of _pretrain_gnn: forward (train-mode dropout), loss = mse(sigmoid(z head_w^T + head_b), rowsum(adj) /
+ * max(1, N)) written to *loss, backward through the GCN, torch.optim.Adam(lr, weight_decay as L2 on the gradient,
+ * betas (0.9, 0.999), eps 1e-8) on the GCN parameters only (the head is not in that optimizer).  The four
+ * parameter tensors must be ONE flat buffer [w1 | b1 | w2 | b2]; exp_avg / exp_avg_sq have that layout; `step`
+ * is 1-based; z receives the forward output of this step. */
+int ufnd_gcn_pretrain_step(const float* x, const float* adj, int ld_adj, const ufnd_gcn_params* p, float* exp_avg,
+                           float* exp_avg_sq, const float* head_w, const float* head_b, float* z, float* workspace, int N,
+                           int in_dim, int hid, int out_dim, float dropout_p, float lr, float weight_decay, int step,
+                           const ufnd_step_state* state, float* loss, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,8 @@ What it does
            tensors, per-tensor digests for grads/params) in tier_a_B*.npz.
   metrics  runs the reference's forensic_metrics on known inputs -> metrics_kat.json.
   temporal runs the reference's TemporalSyncNet.align on seeded weights -> temporal.npz.
+  gcn      runs the reference's build_adj_from_ocr / SimpleGCN (forward, two Adam pre-training steps with
+           dropout p=0) on synthetic phrase sets -> gcn.npz.
   tier_b   builds the locally installed third-party BertModel / CLIPVisionModelWithProjection
            from local configs (2 layers, small vocab; no from_pretrained), loads
            oracle.encoders_ref.seeded_weights, stores inputs + outputs in tier_b.npz and
@@ -340,10 +342,72 @@ def temporal():
     print("temporal: oracle-vs-reference max-abs-err", (ref - ora).abs().max().item())
 
 
+def gcn():
+    """Graph side of the trainer: build_adj_from_ocr, SimpleGCN.forward and the degree
+    pre-training steps (src/training/forensic_trainer.py:25-53,114-132,214-224)."""
+    sys.modules["transformers"] = None
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, str(REF))
+    os.chdir(REF)
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from src.training.forensic_trainer import SimpleGCN, build_adj_from_ocr
+    from oracle import gcn_ref as G
+    N = 150
+    sets = G.synthetic_ocr_sets(N, seed=61)
+    ref_adj = build_adj_from_ocr([set(f"phrase{t}" for t in s) for s in sets], thresh=0.12)     # the reference sees strings
+    assert np.array_equal(ref_adj, G.build_adj_from_ocr(sets, 0.12))
+    for thr in (0.05, 0.3):
+        assert np.array_equal(build_adj_from_ocr([set(f"phrase{t}" for t in s) for s in sets], thresh=thr), G.build_adj_from_ocr(sets, thr))
+    g = torch.Generator().manual_seed(62)
+    T, A, V, U = (torch.randn(N, d, generator=g).numpy() for d in (768, 128, 512, 256))
+    X = G.node_features(T, A, V, U)
+    w = G.seeded_weights(63)
+    net = SimpleGCN(in_dim=416, hid=256, out_dim=128, dropout=0.2).eval()
+    assert list(net.state_dict().keys()) == list(w.keys())
+    net.load_state_dict(w)
+    adj_t, x_t = torch.from_numpy(ref_adj), torch.from_numpy(X)
+    with torch.no_grad():
+        z_ref = net(x_t, adj_t)
+    z_ora = G.gcn_forward(w, x_t, adj_t)
+    e_fwd = (z_ref - z_ora).abs().max().item()
+    assert e_fwd <= 2e-6, e_fwd
+    # the two pre-training steps (:214-224), dropout p = 0 so that the result is RNG-free
+    net.train()
+    net.drop.p = 0.0
+    hg = torch.Generator().manual_seed(64)
+    head = nn.Linear(128, 1)
+    with torch.no_grad():
+        head.weight.copy_(torch.randn(1, 128, generator=hg) * 0.1)
+        head.bias.copy_(torch.randn(1, generator=hg) * 0.1)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-4)
+    target_deg = adj_t.sum(dim=-1, keepdim=True) / max(1.0, adj_t.shape[0])
+    losses = []
+    for _ in range(2):
+        Z = net(x_t, adj_t)
+        loss = F.mse_loss(torch.sigmoid(head(Z)), target_deg)
+        opt.zero_grad(); loss.backward(); opt.step()
+        losses.append(float(loss))
+    w2, l2 = G.pretrain(w, x_t, adj_t, head.weight.detach(), head.bias.detach(), epochs=2)
+    e_pre = max((net.state_dict()[k] - w2[k]).abs().max().item() for k in w)
+    assert e_pre <= 2e-6 and max(abs(a - b) for a, b in zip(losses, l2)) <= 1e-6, (e_pre, losses, l2)
+    with torch.no_grad():
+        net.eval()
+        z_after = net(x_t, adj_t)
+    offs, toks = G.sets_to_csr(sets)
+    np.savez_compressed(HERE / "gcn.npz", N=np.int64(N), set_seed=np.int64(61), weight_seed=np.int64(63), offsets=offs, tokens=toks,
+                        adj_rowsum=ref_adj.sum(1), adj_packed=np.packbits(ref_adj.astype(np.uint8), axis=1), T=T[:, :192], A=A[:, :32],
+                        V=V[:, :128], U=U[:, :64], X=X, Z=z_ref.numpy(), head_w=head.weight.detach().numpy(),
+                        head_b=head.bias.detach().numpy(), losses=np.asarray(losses), Z_after=z_after.numpy(),
+                        lin1_w_after_sum=np.float64(net.lin1.weight.double().sum()), lin2_w_after_sum=np.float64(net.lin2.weight.double().sum()),
+                        checksum=np.float64(sum(x.double().sum() for x in w.values())))
+    print(f"gcn: N={N}, edges={int((ref_adj.sum() - N) / 2)}, forward oracle-vs-reference {e_fwd:.2e}, pretrain {e_pre:.2e}, losses {losses}")
+
+
 if __name__ == "__main__":
     part = sys.argv[1] if len(sys.argv) > 1 else "all"
     if part == "all":
-        for p in ("tier_a", "metrics", "tier_b", "temporal", "init_parity"):
+        for p in ("tier_a", "metrics", "tier_b", "temporal", "init_parity", "gcn"):
             subprocess.check_call([sys.executable, str(Path(__file__).resolve()), p], cwd=str(REPO))
     else:
-        {"tier_a": tier_a, "metrics": metrics, "tier_b": tier_b, "temporal": temporal, "init_parity": init_parity}[part]()
+        {"tier_a": tier_a, "metrics": metrics, "tier_b": tier_b, "temporal": temporal, "init_parity": init_parity, "gcn": gcn}[part]()

@@ -43,8 +43,27 @@ def _base_lib(path):
     return lib
 
 
+def run_ln(A, W, bias, ob, M, N, K, name):
+    """the LayerNorm-aware entry (automatic tile) with the epilogue the folded encoders use for this shape"""
+    import ctypes
+    act, res = REAL.get(name, (0, False))
+    ln = L.GemmLn()
+    ln.a_eps = ln.r_eps = 1e-5
+    ln.width = 768
+    if res:      # residual through LayerNorm + bf16 copy + row statistics out
+        ln.r_stats, ln.r_gamma, ln.r_beta, ln.r_parts, ln.out_stats = ST.data_ptr(), GB.data_ptr(), GB.data_ptr(), 24, STO.data_ptr()
+        L.check(L.lib().ufnd_gemm_bf16_ln(A.data_ptr(), W.data_ptr(), bias.data_ptr(), RES.data_ptr(), ob.data_ptr(), OF.data_ptr(), M, N, K,
+                                          K, K, N, N, N, act, ctypes.byref(ln), L.stream_ptr(A.device)), "gemm_ln")
+    else:        # LayerNorm of the A operand folded in
+        ln.a_stats, ln.colsum, ln.a_parts = ST.data_ptr(), GB.data_ptr(), 24
+        L.check(L.lib().ufnd_gemm_bf16_ln(A.data_ptr(), W.data_ptr(), bias.data_ptr(), None, ob.data_ptr(), None, M, N, K,
+                                          K, K, 0, N, 0, act, ctypes.byref(ln), L.stream_ptr(A.device)), "gemm_ln")
+
+
 def run(cfg, A, W, bias, ob, M, N, K, name=None):
     act, res = REAL.get(name, (0, False))
+    if cfg == 5000:
+        return run_ln(A, W, bias, ob, M, N, K, name)
     if cfg >= 10000:     # the baseline library's tile `cfg - 10000` (its +1000 = software-pipelined schedule)
         r, o, f = (RES.data_ptr(), None, OF.data_ptr()) if res else (None, ob.data_ptr(), None)
         rc = BASE.ufnd_gemm_bf16_ex(A.data_ptr(), W.data_ptr(), bias.data_ptr(), r, o, f, M, N, K, K, K, N if res else 0, 0 if res else N,
@@ -71,7 +90,10 @@ def empty_pair_ms():
 
 
 def main():
-    global RES, OF, BASE
+    global RES, OF, BASE, ST, GB, STO
+    ST = torch.rand(4096, 24, 2, device=DEV) + 1.0
+    GB = torch.rand(3072, device=DEV)
+    STO = torch.empty(4096, 24, 2, device=DEV)
     base_cfgs = []
     for a in sys.argv:
         if a.startswith("--base="):
@@ -112,6 +134,8 @@ def main():
         variants = list(cfgs)
         if BASE is not None:
             variants += [10000 + c for c in base_cfgs if N % TILES[c % 1000][1] == 0]
+        if "--ln" in sys.argv:
+            variants += [5000]
         if ablate:
             variants += [100 + c for c in cfgs] + [200 + c for c in cfgs]
         times = {c: [] for c in variants}
@@ -134,13 +158,15 @@ def main():
         for c in variants:
             t = sorted(times[c])
             med = t[len(t) // 2] * 1e-3
-            if c >= 10000:
+            if c == 5000:
+                bm, bn, tag = 0, 1, "LN-aware entry (auto tile)"
+            elif c >= 10000:
                 bm, bn, lay = TILES[c % 1000]
                 tag = f"BASE {c % 1000}:{bm}x{bn}" + ("-sched" if (c - 10000) >= 1000 else "")
             else:
                 bm, bn, lay = TILES[c % 100]
                 tag = f"{c % 100}:{bm}x{bn}/{lay}" + {0: "", 1: "-noMFMA", 2: "-noDMA"}[(c % 1000) // 100]
-            tiles = -(-M // bm) * (N // bn)
+            tiles = -(-M // bm) * (N // bn) if bm else 0
             row[tag] = {"us": round(med * 1e6, 2), "tflops": round(2.0 * M * N * K / med / 1e12, 1), "tiles": tiles}
         out[name] = row
         print(f"== {name} M={M} N={N} K={K} (empty event pair {empty * 1e3:.1f} us)")

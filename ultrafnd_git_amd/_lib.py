@@ -49,6 +49,10 @@ class ClfParams(C.Structure):
                                    "bypass_w", "bypass_b", "temperature")]
 
 
+class GcnParams(C.Structure):
+    _fields_ = [(n, _FP) for n in ("w1", "b1", "w2", "b2")]
+
+
 class GemmLn(C.Structure):
     """ufnd_gemm_ln: the LayerNorm extras of ufnd_gemm_bf16_ln."""
     _fields_ = [("a_stats", _FP), ("colsum", _FP), ("r_stats", _FP), ("r_gamma", _FP), ("r_beta", _FP), ("out_stats", _FP),
@@ -112,6 +116,15 @@ def _declare_encoders(lib: C.CDLL) -> None:
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = I
+    D = C.c_double
+    lib.ufnd_ocr_adjacency.argtypes = [P, P, I, D, P, I, P]
+    lib.ufnd_ocr_adjacency.restype = I
+    lib.ufnd_gcn_workspace_floats.argtypes = [I, I, I, I, I]
+    lib.ufnd_gcn_workspace_floats.restype = S
+    lib.ufnd_gcn_forward.argtypes = [P, P, I, C.POINTER(GcnParams), P, P, I, I, I, I, F, P, P]
+    lib.ufnd_gcn_forward.restype = I
+    lib.ufnd_gcn_pretrain_step.argtypes = [P, P, I, C.POINTER(GcnParams), P, P, P, P, P, P, I, I, I, I, F, F, F, I, P, P, P]
+    lib.ufnd_gcn_pretrain_step.restype = I
     lib.ufnd_temporal_weight_ld.argtypes = [I]
     lib.ufnd_temporal_weight_ld.restype = I
     lib.ufnd_temporal_workspace_floats.argtypes = [I, I, I]

@@ -47,16 +47,33 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return cdf + x * pdf;
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
-// bf16-output epilogues: v_exp + v_rcp (1 ulp) instead of the IEEE division sequence
-__device__ __forceinline__ float sigmoid_fast_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+// bf16-output epilogues.  Contraction is switched OFF inside them (HIP's __fmul_rn / __fadd_rn are plain
+// operators, which the compiler may still fuse differently per kernel instantiation) and every fused
+// multiply-add is spelled out: every GEMM tile shape must emit the same operation sequence, so that a
+// row's result never depends on the batch it is computed in.
+// v_exp + v_rcp (1 ulp) instead of the IEEE division ladder.
+__device__ __forceinline__ float sigmoid_fast_f(float x) {
+#pragma clang fp contract(off)
+  return __builtin_amdgcn_rcpf(__fadd_rn(1.0f, __expf(-x)));
+}
+__device__ __forceinline__ float quick_gelu_fast_f(float x) {      // x * sigmoid(1.702 x)
+#pragma clang fp contract(off)
+  return __fmul_rn(x, sigmoid_fast_f(__fmul_rn(1.702f, x)));
+}
 // erf-GELU for bf16 outputs: Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7, far below a bf16 ulp),
-// one v_exp + one v_rcp + 7 FMAs instead of libm's erff polynomial ladder.
+// one v_exp + one v_rcp + 8 FMAs instead of libm's erff polynomial ladder.
 __device__ __forceinline__ float gelu_fast_f(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);   // v_rcp_f32 (1 ulp); __frcp_rn expands to the IEEE division ladder
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float erf_abs = 1.0f - poly * __expf(-z * z);
-  return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+#pragma clang fp contract(off)
+  const float z = __fmul_rn(fabsf(x), 0.70710678118654752440f);
+  const float t = __builtin_amdgcn_rcpf(__fmaf_rn(0.3275911f, z, 1.0f));   // v_rcp_f32; __frcp_rn expands to the division ladder
+  float p = __fmaf_rn(t, 1.061405429f, -1.453152027f);
+  p = __fmaf_rn(t, p, 1.421413741f);
+  p = __fmaf_rn(t, p, -0.284496736f);
+  p = __fmaf_rn(t, p, 0.254829592f);
+  const float poly = __fmul_rn(t, p);
+  const float erf_abs = __fmaf_rn(-poly, __expf(__fmul_rn(-z, z)), 1.0f);
+  const float h = __fmul_rn(0.5f, x);
+  return __fmaf_rn(h, copysignf(erf_abs, x), h);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -17,6 +17,10 @@
 
 #include "common.hpp"
 
+// No implicit contraction in this file: the epilogues spell every fused multiply-add out (fmaf), so that
+// all tile shapes emit the same floating-point operation sequence (rows are batch-invariant, bit for bit).
+#pragma clang fp contract(off)
+
 namespace {
 
 constexpr int BK = 64;
@@ -46,6 +50,12 @@ struct GemmArgs {
 __device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst) {
   __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gsrc,
                                    (void __attribute__((address_space(3)))*)lds_dst, 16, 0, 0);
+}
+
+// value barrier: keeps the backend from fusing the producer of x into a later add (zero instructions)
+__device__ __forceinline__ float opaque_f(float x) {
+  asm volatile("" : "+v"(x));
+  return x;
 }
 
 __device__ __forceinline__ bf16x8 lds_frag(const char* tile, int row, int chunk) {
@@ -304,9 +314,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         sm = s01 + s23;
         sq = q01 + q23;
       }
-      const float mean = sm * a.inv_h;
-      const float var = fmaxf(sq * a.inv_h - mean * mean, 0.f);
-      if (threadIdx.x % TPR == 0) st_lds[threadIdx.x / TPR] = f32x2{mean, 1.0f / sqrtf(var + (a.a_stats ? a.a_eps : a.r_eps))};
+      const float mean = __fmul_rn(sm, a.inv_h);
+      const float var = fmaxf(__fmaf_rn(-mean, mean, __fmul_rn(sq, a.inv_h)), 0.f);
+      if (threadIdx.x % TPR == 0) st_lds[threadIdx.x / TPR] = f32x2{mean, __frcp_rn(__fsqrt_rn(__fadd_rn(var, a.a_stats ? a.a_eps : a.r_eps)))};
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   }
@@ -321,98 +331,117 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
   // ---- epilogue.  Bias and activation are elementwise, so they run on the accumulators where they
   // lie (straight-line VALU, no LDS dependency); only the layout change for whole-row stores goes
   // through a wave-private LDS patch, 16 rows at a time, where the fp32 residual is added.
-  float bj[NT];
+  // per-column vectors of this lane's accumulator columns (col_j = n0 + wn*TN + j*MI + fr), loaded once
+  float bj[NT], csj[NT];
 #pragma unroll
-  for (int j = 0; j < NT; ++j) bj[j] = 0.f;
+  for (int j = 0; j < NT; ++j) { bj[j] = 0.f; csj[j] = 0.f; }
   if (a.bias) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) bj[j] = a.bias[n0 + wn * TN + j * MI + fr];
   }
+  bool fold = false, rln = false;
+  if constexpr (LNX) {
+    fold = a.a_stats != nullptr;
+    rln = a.r_stats != nullptr;
+    if (fold) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) csj[j] = a.colsum[n0 + wn * TN + j * MI + fr];
+    }
+  }
   float* cst = reinterpret_cast<float*>(smem) + wave * MI * CP;
   constexpr int CPR = TN / 8;                    // 8-column chunks per row
   constexpr int CHUNKS = MI * CPR;               // chunks per MI-row patch
+  constexpr int NIT = (CHUNKS + 63) / 64;        // row-phase iterations per patch
+  constexpr bool FIXCOL = (64 % CPR) == 0;       // a lane keeps its 8 columns across the iterations
+  auto ld8 = [&](const float* ptr, float (&o)[8]) {
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(ptr), x1 = *reinterpret_cast<const f32x4*>(ptr + 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { o[q] = x0[q]; o[4 + q] = x1[q]; }
+  };
+  float g8[8], b8[8];                            // LNX, FIXCOL: gamma / beta of the residual's LayerNorm for my columns
+  if constexpr (LNX && FIXCOL) {
+    if (rln) {
+      const int col = n0 + wn * TN + (lane % CPR) * 8;
+      ld8(a.r_gamma + col, g8);
+      ld8(a.r_beta + col, b8);
+    }
+  }
   auto epilogue = [&](auto act_) {
     constexpr int ACT = decltype(act_)::value;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      // bias + activation of row-tile i on the accumulators (VALU), beside the stores of row-tile i-1
+      // the residual rows of this patch are requested first: they land while the patch is staged
+      float rr8[NIT][8];
+      if (a.residual) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int r = 0; r < AR; ++r) {
-          float v = acc[i][j][r];
-          if constexpr (!LNX) {     // (LNX: bias and activation follow the folded normalisation, in the row phase)
-            v += bj[j];
-            if constexpr (ACT == UFND_ACT_GELU) v = gelu_fast_f(v);
-            else if constexpr (ACT == UFND_ACT_QUICK_GELU) v = v * sigmoid_fast_f(1.702f * v);
+        for (int it = 0; it < NIT; ++it) {
+          const int id = lane + 64 * it;
+          if (id < CHUNKS) {
+            int row = m0 + wm * TM + i * MI + id / CPR;
+            row = row < a.M ? row : a.M - 1;
+            ld8(a.residual + (size_t)row * a.ldr + n0 + wn * TN + (id % CPR) * 8, rr8[it]);
           }
-          // accumulator register r of lane (fr, g): 16x16 -> row 4g + r; 32x32 -> row 8(r>>2) + 4g + (r&3)
-          const int prow_ = MI == 16 ? 4 * g + r : 8 * (r >> 2) + 4 * g + (r & 3);
+        }
+      }
+      // register phase: [folded LayerNorm of the A operand,] bias, activation on the accumulators where they lie
+#pragma unroll
+      for (int r = 0; r < AR; ++r) {
+        // accumulator register r of lane (fr, g): 16x16 -> row 4g + r; 32x32 -> row 8(r>>2) + 4g + (r&3)
+        const int prow_ = MI == 16 ? 4 * g + r : 8 * (r >> 2) + 4 * g + (r & 3);
+        f32x2 ms = {0.f, 1.f};
+        if constexpr (LNX) {
+          if (fold) ms = st_lds[wm * TM + i * MI + prow_];      // {mean, rstd} of the row
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          float v = acc[i][j][r];
+          if constexpr (LNX) {
+            // LayerNorm(A) W'^T = rstd (A W'^T - mean colsum(W')); explicit roundings: every tile shape must
+            // emit the same operation sequence (rows stay batch-invariant)
+            // (opaque(): the product must not be re-fused with the bias add below -- the backend did so
+            //  for a few elements of some tile shapes even with contraction switched off in the source)
+            if (fold) v = opaque_f(__fmul_rn(ms[1], __fmaf_rn(-ms[0], csj[j], v)));
+          }
+          v = __fadd_rn(v, bj[j]);
+          if constexpr (ACT == UFND_ACT_GELU) v = gelu_fast_f(v);
+          else if constexpr (ACT == UFND_ACT_QUICK_GELU) v = quick_gelu_fast_f(v);
           cst[prow_ * CP + j * MI + fr] = v;
         }
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // row phase: whole rows out of the wave's patch: residual, statistics, 16-B / 32-B stores
 #pragma unroll
-      for (int it = 0; it < (CHUNKS + 63) / 64; ++it) {
+      for (int it = 0; it < NIT; ++it) {
         const int id = lane + 64 * it;
         if (id >= CHUNKS) break;
         const int rr = id / CPR, cl = (id % CPR) * 8;
         const int row = m0 + wm * TM + i * MI + rr;
         const int col = n0 + wn * TN + cl;
+        const bool live = row < a.M;
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(cst + rr * CP + cl);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(cst + rr * CP + cl + 4);
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        if constexpr (!LNX) {
-          if (row >= a.M) continue;
-          if (a.residual) {
-            const float* rp = a.residual + (size_t)row * a.ldr + col;
-            const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+        if (a.residual) {
+          if constexpr (LNX) {
+            if (rln) {      // the residual stream is LayerNorm(residual) * gamma + beta, never materialised
+              const f32x2 ms = st_lds[wm * TM + i * MI + rr];
+              if constexpr (!FIXCOL) {
+                ld8(a.r_gamma + col, g8);
+                ld8(a.r_beta + col, b8);
+              }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { v[q] += r0[q]; v[4 + q] += r1[q]; }
-          }
-        } else {
-          const bool live = row < a.M;
-          const int rowc = live ? row : a.M - 1;
-          const f32x2 ms = st_lds[rowc - m0];           // {mean, rstd} of this row (a_stats or r_stats)
-          auto ld8 = [&](const float* ptr, float (&o)[8]) {
-            const f32x4 x0 = *reinterpret_cast<const f32x4*>(ptr), x1 = *reinterpret_cast<const f32x4*>(ptr + 4);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { o[q] = x0[q]; o[4 + q] = x1[q]; }
-          };
-          if (a.a_stats) {        // LayerNorm(A) W'^T = rstd (A W'^T - mean colsum(W'))
-            float cs[8];
-            ld8(a.colsum + col, cs);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = ms[1] * (v[q] - ms[0] * cs[q]);
-          }
-          if (a.bias) {
-            float bb[8];
-            ld8(a.bias + col, bb);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] += bb[q];
-          }
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            if constexpr (ACT == UFND_ACT_GELU) v[q] = gelu_fast_f(v[q]);
-            else if constexpr (ACT == UFND_ACT_QUICK_GELU) v[q] = v[q] * sigmoid_fast_f(1.702f * v[q]);
-          }
-          if (a.residual) {
-            float rr8[8];
-            ld8(a.residual + (size_t)rowc * a.ldr + col, rr8);
-            if (a.r_stats) {      // the residual stream is LayerNorm(residual) * gamma + beta, never materialised
-              float gg[8], be[8];
-              ld8(a.r_gamma + col, gg);
-              ld8(a.r_beta + col, be);
-#pragma unroll
-              for (int q = 0; q < 8; ++q) rr8[q] = (rr8[q] - ms[0]) * ms[1] * gg[q] + be[q];
+              for (int q = 0; q < 8; ++q) rr8[it][q] = __fmaf_rn(__fmul_rn(__fsub_rn(rr8[it][q], ms[0]), ms[1]), g8[q], b8[q]);
             }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] += rr8[q];
           }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = __fadd_rn(v[q], rr8[it][q]);
+        }
+        if constexpr (LNX) {
           if (a.out_stats) {      // partial {sum, sumsq} of the fp32 output row over each aligned 32-column group
             if constexpr (CPR % 4 == 0) {   // (canonical: the partial of columns [32p, 32p+32) never depends on the tile shape)
               float sm = 0.f, sq = 0.f;
 #pragma unroll
-              for (int q = 0; q < 8; ++q) { sm += v[q]; sq += v[q] * v[q]; }
+              for (int q = 0; q < 8; ++q) { sm = __fadd_rn(sm, v[q]); sq = __fmaf_rn(v[q], v[q], sq); }
               sm += __shfl_xor(sm, 1, 64);
               sq += __shfl_xor(sq, 1, 64);
               sm += __shfl_xor(sm, 2, 64);
@@ -421,8 +450,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 *reinterpret_cast<f32x2*>(a.out_stats + ((size_t)row * (a.N >> 5) + (col >> 5)) * 2) = f32x2{sm, sq};
             }
           }
-          if (!live) continue;
         }
+        if (!live) continue;
         if (a.out_f32) {
           float* op = a.out_f32 + (size_t)ks * a.M * a.ldf + (size_t)row * a.ldf + col;
           *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};

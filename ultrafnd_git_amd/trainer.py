@@ -167,12 +167,18 @@ class ForensicTrainer:
         if not cfg.use_gnn:
             raise ValueError("use_gnn=False: the reference's fusion head is sized for the concat WITH the GNN slot and "
                              "fails in forward without gnn_feat (cross_modal_transformer.py:184-197); not supported")
+        self.gnn = None   # the GCN that produced gnn_Z is not part of the step (its output is detached: :209-211)
         if "gnn_Z" not in cache:
-            raise KeyError("cache['gnn_Z'] (N, gnn_dim) is required: SimpleGCN pre-training is init-time work outside "
-                           "this package's scope (SURVEY.md section 2 row 2)")
+            if "ocr_sets" not in cache:
+                raise KeyError("cache needs either 'gnn_Z' (N, gnn_dim) or 'ocr_sets' (N phrase sets) to build it from "
+                               "(forensic_trainer.py:184-211)")
+            # ForensicTrainer._build_gnn: node features, OCR-Jaccard adjacency, SimpleGCN, two pre-training steps
+            from .gcn import build_gnn_embeddings
+            self.gnn, self.X, self.Adj, Z = build_gnn_embeddings(cache, cfg.gnn_dim, cfg.gnn_overlap_thresh, self.device)
+            cache = dict(cache)
+            cache["gnn_Z"] = Z.detach()
         self.cache = cache
         (self.tr_idx, self.va_idx, self.te_idx) = cache["split"]
-        self.gnn = None   # the GCN that produced gnn_Z is not part of the step
 
         self.train_loader, self.val_loader, self.test_loader = self._build_dataloaders()
 
@@ -583,7 +589,7 @@ class ForensicTrainer:
                 if self.rank == 0:
                     torch.save({"fusion": {k: v.cpu() for k, v in self.fusion.state_dict().items()},
                                 "clf": {k: v.cpu() for k, v in self.clf.state_dict().items()},
-                                "gnn": None, "cfg": dict(self.cfg.__dict__)}, self.ckpt_path)
+                                "gnn": self.gnn.state_dict() if self.gnn is not None else None, "cfg": dict(self.cfg.__dict__)}, self.ckpt_path)
                     print(f"  ↳ saved best checkpoint to {self.ckpt_path} (val_auc={self.best_val_auc:.3f})")
             else:
                 self.no_improve += 1
