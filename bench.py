@@ -189,6 +189,7 @@ def main():
                 "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
                 "launches_per_step": n_launch, "avg_launch_us": round(gem_ms * 1e3 / n_launch, 2),
                 "gemm_ms_per_step": round(gem_ms, 4), "flops_per_launch_avg": flops / n_launch,
+                "event_marker_us": round(tr.last_marker_us, 2),
                 "by_shape_MxNxK": {k: {"launches_per_step": v[0] // 3, "avg_us": round(v[1] / v[0] * 1e3, 2),
                                        "tflops": round(2.0 * eval(k.replace("x", "*")) / (v[1] / v[0] * 1e-3) / 1e12, 1)}
                                    for k, v in tr.last_gemm_by_shape.items()}}

@@ -166,12 +166,96 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
       dma16(a.W + (size_t)gr * a.ldw + k0 + c * 8, buf + p * 1024);
     }
   };
+  // LNX: the producers' partial {sum, sumsq} of my tile's rows become {mean, rstd} in LDS.  The loads are
+  // the kernel's FIRST memory operations (older than every DMA piece, so the counted vmcnt waits of the
+  // K loop are not disturbed) and are consumed while the first stages fly -- their latency hides behind
+  // the wait for stage 0, which every block pays anyway.  The summation order is CANONICAL -- 16-B chunk c (two
+  // partials) belongs to group c % 4, a group adds its chunks in ascending order, the total is
+  // (g0 + g1) + (g2 + g3) -- whatever the tile shape, so a row's statistics (hence its outputs) do
+  // not depend on the batch it is computed in.  No atomics.
+  constexpr int TPR = NW * 64 / BM;                 // threads per tile row: 2 or 4
+  static_assert(!LNX || TPR == 2 || TPR == 4, "threads per tile row");
+  constexpr int GPT = 4 / (TPR < 4 ? TPR : 4);      // groups per thread
+  f32x4 sv[GPT][3];
+  f32x2* st_lds = reinterpret_cast<f32x2*>(smem + STAT_OFF);
+  const float* sp = nullptr;
+  if constexpr (LNX) {
+    sp = a.a_stats ? a.a_stats : a.r_stats;
+    if (sp) {
+      const int parts = a.a_stats ? a.a_parts : a.r_parts;
+      int row = m0 + (int)threadIdx.x / TPR;
+      row = row < a.M ? row : a.M - 1;
+      const f32x4* base = reinterpret_cast<const f32x4*>(sp + (size_t)row * parts * 2);
+      const int nq = parts >> 1, sub = threadIdx.x % TPR;
+#pragma unroll
+      for (int gi = 0; gi < GPT; ++gi)
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const int q = (sub + gi * TPR) + 4 * u;     // chunks of group sub + gi*TPR
+          // unconditional (clamped) loads, issued back to back and masked at use.  Inline asm: the compiler's
+          // own vmcnt bookkeeping would put s_waitcnt vmcnt(0) in front of their first use, i.e. also wait for
+          // every prologue DMA stage; stats_wait() below waits for exactly these loads.
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sv[gi][u]) : "v"(base + (q < nq ? q : 0)) : "memory");
+        }
+    }
+  }
   // prologue: every ring slot is filled (W(s) before A(s), step by step, so that a counted vmcnt
   // separates "steps <= t+1" from the later ones)
 #pragma unroll
   for (int s = 0; s < STA; ++s) {
     if (s < STB && s < nk) issueB(s);
     if (s < nk) issueA(s);
+  }
+
+  if constexpr (LNX) {
+    if (sp) {
+      // the statistics loads are older than every prologue DMA piece: wait until at most those pieces are
+      // outstanding (the loaded registers are operands, so nothing that reads them can move above the wait)
+      constexpr int NPRO = STA * PWA + STB * PWB;
+      static_assert(NPRO <= 63, "vmcnt range");
+      if (STA <= nk) {
+        if constexpr (GPT == 1)
+          asm volatile("s_waitcnt vmcnt(%3)" : "+v"(sv[0][0]), "+v"(sv[0][1]), "+v"(sv[0][2]) : "n"(NPRO) : "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(%6)" : "+v"(sv[0][0]), "+v"(sv[0][1]), "+v"(sv[0][2]), "+v"(sv[GPT - 1][0]), "+v"(sv[GPT - 1][1]),
+                       "+v"(sv[GPT - 1][2]) : "n"(NPRO) : "memory");
+      } else {
+        if constexpr (GPT == 1)
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(sv[0][0]), "+v"(sv[0][1]), "+v"(sv[0][2]) : : "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(sv[0][0]), "+v"(sv[0][1]), "+v"(sv[0][2]), "+v"(sv[GPT - 1][0]), "+v"(sv[GPT - 1][1]),
+                       "+v"(sv[GPT - 1][2]) : : "memory");
+      }
+      const int nq_ = (a.a_stats ? a.a_parts : a.r_parts) >> 1, sub_ = threadIdx.x % TPR;
+      float gs[GPT], gq[GPT];
+#pragma unroll
+      for (int gi = 0; gi < GPT; ++gi) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          if ((sub_ + gi * TPR) + 4 * u >= nq_) sv[gi][u] = f32x4{0.f, 0.f, 0.f, 0.f};   // chunk beyond the partial count
+        }
+        gs[gi] = sv[gi][0][0] + sv[gi][0][2];
+        gq[gi] = sv[gi][0][1] + sv[gi][0][3];
+#pragma unroll
+        for (int u = 1; u < 3; ++u) { gs[gi] += sv[gi][u][0] + sv[gi][u][2]; gq[gi] += sv[gi][u][1] + sv[gi][u][3]; }
+      }
+      float sm, sq;
+      if constexpr (TPR == 4) {        // lane sub holds group sub
+        sm = gs[0] + __shfl_xor(gs[0], 1, 64);
+        sq = gq[0] + __shfl_xor(gq[0], 1, 64);
+        sm += __shfl_xor(sm, 2, 64);
+        sq += __shfl_xor(sq, 2, 64);
+      } else {                         // lane sub holds groups sub and sub + 2
+        const float s01 = gs[0] + __shfl_xor(gs[0], 1, 64), s23 = gs[1] + __shfl_xor(gs[1], 1, 64);
+        const float q01 = gq[0] + __shfl_xor(gq[0], 1, 64), q23 = gq[1] + __shfl_xor(gq[1], 1, 64);
+        sm = s01 + s23;
+        sq = q01 + q23;
+      }
+      const float mean = __fmul_rn(sm, a.inv_h);
+      const float var = fmaxf(__fmaf_rn(-mean, mean, __fmul_rn(sq, a.inv_h)), 0.f);
+      if (threadIdx.x % TPR == 0) st_lds[threadIdx.x / TPR] = f32x2{mean, __frcp_rn(__fsqrt_rn(__fadd_rn(var, a.a_stats ? a.a_eps : a.r_eps)))};
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
   }
 
   bf16x8 af0[KQ][MT], bf0[KQ][NT], af1[KQ][MT], bf1[KQ][NT];      // fragments of k-half 0 / k-half 1
@@ -262,64 +346,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
   for (; t + STA < nk; ++t) body(t, IntC<1>{}, IntC<1>{}, IntC<1>{});     // steady state
   for (; t + STB < nk; ++t) body(t, IntC<0>{}, IntC<1>{}, IntC<1>{});     // (STA == STB + 1) only W left to fetch
   for (; t + 1 < nk; ++t) body(t, IntC<0>{}, IntC<0>{}, IntC<1>{});       // drain
-  // LNX: the producers' partial {sum, sumsq} of my tile's rows become {mean, rstd} in LDS.  The loads
-  // are issued before the last K-step (no DMA is in flight any more, so they do not disturb the
-  // counted vmcnt) and consumed after it.  The summation order is CANONICAL -- 16-B chunk c (two
-  // partials) belongs to group c % 4, a group adds its chunks in ascending order, the total is
-  // (g0 + g1) + (g2 + g3) -- whatever the tile shape, so a row's statistics (hence its outputs) do
-  // not depend on the batch it is computed in.  No atomics.
-  constexpr int TPR = NW * 64 / BM;                 // threads per tile row: 2 or 4
-  static_assert(!LNX || TPR == 2 || TPR == 4, "threads per tile row");
-  constexpr int GPT = 4 / (TPR < 4 ? TPR : 4);      // groups per thread
-  f32x4 sv[GPT][3];
-  f32x2* st_lds = reinterpret_cast<f32x2*>(smem + STAT_OFF);
-  const float* sp = nullptr;
-  if constexpr (LNX) {
-    sp = a.a_stats ? a.a_stats : a.r_stats;
-    if (sp) {
-      const int parts = a.a_stats ? a.a_parts : a.r_parts;
-      int row = m0 + (int)threadIdx.x / TPR;
-      row = row < a.M ? row : a.M - 1;
-      const f32x4* base = reinterpret_cast<const f32x4*>(sp + (size_t)row * parts * 2);
-      const int nq = parts >> 1, sub = threadIdx.x % TPR;
-#pragma unroll
-      for (int gi = 0; gi < GPT; ++gi)
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-          const int q = (sub + gi * TPR) + 4 * u;     // chunks of group sub + gi*TPR
-          sv[gi][u] = q < nq ? base[q] : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
-  }
   body(t, IntC<0>{}, IntC<0>{}, IntC<0>{});                               // last step: no successor
-  if constexpr (LNX) {
-    if (sp) {
-      float gs[GPT], gq[GPT];
-#pragma unroll
-      for (int gi = 0; gi < GPT; ++gi) {
-        gs[gi] = sv[gi][0][0] + sv[gi][0][2];
-        gq[gi] = sv[gi][0][1] + sv[gi][0][3];
-#pragma unroll
-        for (int u = 1; u < 3; ++u) { gs[gi] += sv[gi][u][0] + sv[gi][u][2]; gq[gi] += sv[gi][u][1] + sv[gi][u][3]; }
-      }
-      float sm, sq;
-      if constexpr (TPR == 4) {        // lane sub holds group sub
-        sm = gs[0] + __shfl_xor(gs[0], 1, 64);
-        sq = gq[0] + __shfl_xor(gq[0], 1, 64);
-        sm += __shfl_xor(sm, 2, 64);
-        sq += __shfl_xor(sq, 2, 64);
-      } else {                         // lane sub holds groups sub and sub + 2
-        const float s01 = gs[0] + __shfl_xor(gs[0], 1, 64), s23 = gs[1] + __shfl_xor(gs[1], 1, 64);
-        const float q01 = gq[0] + __shfl_xor(gq[0], 1, 64), q23 = gq[1] + __shfl_xor(gq[1], 1, 64);
-        sm = s01 + s23;
-        sq = q01 + q23;
-      }
-      const float mean = __fmul_rn(sm, a.inv_h);
-      const float var = fmaxf(__fmaf_rn(-mean, mean, __fmul_rn(sq, a.inv_h)), 0.f);
-      if (threadIdx.x % TPR == 0) st_lds[threadIdx.x / TPR] = f32x2{mean, __frcp_rn(__fsqrt_rn(__fadd_rn(var, a.a_stats ? a.a_eps : a.r_eps)))};
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-  }
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();   // everyone is done reading the ring: reuse it for the epilogue
   __builtin_amdgcn_sched_barrier(0);
@@ -366,8 +393,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
       ld8(a.r_beta + col, b8);
     }
   }
-  auto epilogue = [&](auto act_) {
+  // MODE (LNX kernels): 0 plain, 1 LayerNorm of the A operand folded in, 2 residual through a LayerNorm
+  auto epilogue = [&](auto act_, auto mode_) {
     constexpr int ACT = decltype(act_)::value;
+    constexpr bool FOLD = LNX && decltype(mode_)::value == 1, RLN = LNX && decltype(mode_)::value == 2;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       // the residual rows of this patch are requested first: they land while the patch is staged
@@ -389,19 +418,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         // accumulator register r of lane (fr, g): 16x16 -> row 4g + r; 32x32 -> row 8(r>>2) + 4g + (r&3)
         const int prow_ = MI == 16 ? 4 * g + r : 8 * (r >> 2) + 4 * g + (r & 3);
         f32x2 ms = {0.f, 1.f};
-        if constexpr (LNX) {
-          if (fold) ms = st_lds[wm * TM + i * MI + prow_];      // {mean, rstd} of the row
-        }
+        if constexpr (FOLD) ms = st_lds[wm * TM + i * MI + prow_];      // {mean, rstd} of the row
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           float v = acc[i][j][r];
-          if constexpr (LNX) {
-            // LayerNorm(A) W'^T = rstd (A W'^T - mean colsum(W')); explicit roundings: every tile shape must
-            // emit the same operation sequence (rows stay batch-invariant)
-            // (opaque(): the product must not be re-fused with the bias add below -- the backend did so
-            //  for a few elements of some tile shapes even with contraction switched off in the source)
-            if (fold) v = opaque_f(__fmul_rn(ms[1], __fmaf_rn(-ms[0], csj[j], v)));
-          }
+          // LayerNorm(A) W'^T = rstd (A W'^T - mean colsum(W')); explicit roundings: every tile shape must
+          // emit the same operation sequence (rows stay batch-invariant)
+          // (opaque(): the product must not be re-fused with the bias add below -- the backend did so
+          //  for a few elements of some tile shapes even with contraction switched off in the source)
+          if constexpr (FOLD) v = opaque_f(__fmul_rn(ms[1], __fmaf_rn(-ms[0], csj[j], v)));
           v = __fadd_rn(v, bj[j]);
           if constexpr (ACT == UFND_ACT_GELU) v = gelu_fast_f(v);
           else if constexpr (ACT == UFND_ACT_QUICK_GELU) v = quick_gelu_fast_f(v);
@@ -422,16 +447,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(cst + rr * CP + cl + 4);
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         if (a.residual) {
-          if constexpr (LNX) {
-            if (rln) {      // the residual stream is LayerNorm(residual) * gamma + beta, never materialised
-              const f32x2 ms = st_lds[wm * TM + i * MI + rr];
-              if constexpr (!FIXCOL) {
-                ld8(a.r_gamma + col, g8);
-                ld8(a.r_beta + col, b8);
-              }
-#pragma unroll
-              for (int q = 0; q < 8; ++q) rr8[it][q] = __fmaf_rn(__fmul_rn(__fsub_rn(rr8[it][q], ms[0]), ms[1]), g8[q], b8[q]);
+          if constexpr (RLN) {      // the residual stream is LayerNorm(residual) * gamma + beta, never materialised
+            const f32x2 ms = st_lds[wm * TM + i * MI + rr];
+            if constexpr (!FIXCOL) {
+              ld8(a.r_gamma + col, g8);
+              ld8(a.r_beta + col, b8);
             }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rr8[it][q] = __fmaf_rn(__fmul_rn(__fsub_rn(rr8[it][q], ms[0]), ms[1]), g8[q], b8[q]);
           }
 #pragma unroll
           for (int q = 0; q < 8; ++q) v[q] = __fadd_rn(v[q], rr8[it][q]);
@@ -467,9 +490,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // patch reads done before the next row-tile overwrites it
     }
   };
-  if (a.act == UFND_ACT_GELU) epilogue(IntC<UFND_ACT_GELU>{});
-  else if (a.act == UFND_ACT_QUICK_GELU) epilogue(IntC<UFND_ACT_QUICK_GELU>{});
-  else epilogue(IntC<UFND_ACT_NONE>{});
+  if constexpr (LNX) {
+    if (fold) {
+      if (a.act == UFND_ACT_GELU) epilogue(IntC<UFND_ACT_GELU>{}, IntC<1>{});
+      else if (a.act == UFND_ACT_QUICK_GELU) epilogue(IntC<UFND_ACT_QUICK_GELU>{}, IntC<1>{});
+      else epilogue(IntC<UFND_ACT_NONE>{}, IntC<1>{});
+    } else if (rln) {
+      epilogue(IntC<UFND_ACT_NONE>{}, IntC<2>{});      // (host side: residual-through-LayerNorm calls carry no activation)
+    } else {
+      epilogue(IntC<UFND_ACT_NONE>{}, IntC<0>{});      // (and neither do plain calls of this entry point)
+    }
+  } else {
+    if (a.act == UFND_ACT_GELU) epilogue(IntC<UFND_ACT_GELU>{}, IntC<0>{});
+    else if (a.act == UFND_ACT_QUICK_GELU) epilogue(IntC<UFND_ACT_QUICK_GELU>{}, IntC<0>{});
+    else epilogue(IntC<UFND_ACT_NONE>{}, IntC<0>{});
+  }
   if constexpr (DBG) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp[6] = __builtin_amdgcn_s_memtime();
@@ -646,6 +681,7 @@ extern "C" int ufnd_gemm_bf16_ln(const void* A, const void* W, const float* bias
   UFND_REQUIRE(!bias || ufnd_aligned(bias, 16), "gemm_bf16_ln: bias must be 16-B aligned");
   UFND_REQUIRE(act >= 0 && act <= 2, "gemm_bf16_ln: act=%d", act);
   UFND_REQUIRE(!(ln->a_stats && ln->r_stats), "gemm_bf16_ln: a_stats and r_stats are mutually exclusive");
+  UFND_REQUIRE(ln->a_stats || act == UFND_ACT_NONE, "gemm_bf16_ln: an activation is only fused together with a folded LayerNorm (a_stats)");
   UFND_REQUIRE(ln->width > 0, "gemm_bf16_ln: width (the LayerNorm dimension) must be positive");
   if (ln->a_stats) {
     UFND_REQUIRE(ln->colsum && ufnd_aligned(ln->colsum, 16) && ufnd_aligned(ln->a_stats, 16), "gemm_bf16_ln: colsum / a_stats alignment");

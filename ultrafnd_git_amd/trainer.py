@@ -475,6 +475,7 @@ class ForensicTrainer:
         events: List[Tuple[torch.cuda.Event, torch.cuda.Event]] = []
         shapes: List[Tuple[int, int, int]] = []
         originals = []
+        passes: List[Tuple[int, int]] = []
         for enc in (self.text_encoder, self.visual_encoder):
             for name in ("_gemm", "_gemm_ln"):       # the plain and the LayerNorm-aware entry: the same kernel family
                 orig = getattr(enc, name)
@@ -490,31 +491,33 @@ class ForensicTrainer:
                 setattr(enc, name, timed)
         try:
             for _ in range(steps):
-                # park the GPU behind a ~4 ms spin so the host has every launch and event of the pass queued
+                # park the GPU behind a ~12 ms spin so the host has every launch and event of the pass queued
                 # before the GPU reaches them: event deltas then measure GPU time, not host enqueue latency
-                torch.cuda._sleep(8_000_000)
-                self.text_encoder(batch["input_ids"], batch["attention_mask"])
-                torch.cuda._sleep(8_000_000)
-                self.visual_encoder(batch["frames"])
+                for enc, args in ((self.text_encoder, (batch["input_ids"], batch["attention_mask"])), (self.visual_encoder, (batch["frames"],))):
+                    torch.cuda._sleep(24_000_000)
+                    mark = len(events)
+                    enc(*args)
+                    passes.append((mark, len(events)))
             torch.cuda.synchronize(self.device)
         finally:
             for enc, name, orig in originals:
                 setattr(enc, name, orig)
-        # an event pair around nothing still reads a few us: calibrate it and take it off each launch
-        pairs = []
-        for _ in range(64):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            e1.record()
-            pairs.append((e0, e1))
-        torch.cuda.synchronize(self.device)
-        empty = sorted(e0.elapsed_time(e1) for e0, e1 in pairs)[len(pairs) // 2]
-        total = sum(max(0.0, e0.elapsed_time(e1) - empty) for e0, e1 in events)
+        # An event costs the queue a marker packet.  Its price is taken IN SITU: where two GEMMs follow each other
+        # with nothing in between, (end event of the first -> start event of the second) is exactly one
+        # marker-to-marker interval of the busy queue; the lower quartile of all such gaps of a pass is that price
+        # (the other gaps contain an attention / LayerNorm kernel).  launch duration = (end - start) - price.
+        gaps = []
+        for lo, hi in passes:
+            gaps += [events[k][1].elapsed_time(events[k + 1][0]) for k in range(lo, hi - 1)]
+        gaps.sort()
+        marker = gaps[len(gaps) // 4] if gaps else 0.0
+        self.last_marker_us = marker * 1e3
+        total = sum(max(0.0, e0.elapsed_time(e1) - marker) for e0, e1 in events)
         self.last_gemm_by_shape = {}
         for (e0, e1), shp in zip(events, shapes):
             d = self.last_gemm_by_shape.setdefault("x".join(map(str, shp)), [0, 0.0])
             d[0] += 1
-            d[1] += max(0.0, e0.elapsed_time(e1) - empty)
+            d[1] += max(0.0, e0.elapsed_time(e1) - marker)
         return total / steps, len(events) // steps
 
     def _forward_batch(self, batch, split: str) -> Dict[str, torch.Tensor]:
