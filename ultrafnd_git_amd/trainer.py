@@ -350,10 +350,9 @@ class ForensicTrainer:
                 "text_out": torch.empty(B, 768, dtype=torch.float32, device=dev),
                 "vis_out": torch.empty(B, 512, dtype=torch.float32, device=dev), "g_text": None, "g_vis": None}
         if self._enc_streams is None:
-            # the text encoder is the long pole of the step (its stream never idles): it gets the high-priority
-            # queue, the visual encoder and the head fill the CUs it leaves free
-            pt, pv = (int(x) for x in os.environ.get("UFND_ENC_PRIO", "-1,0").split(","))
-            self._enc_streams = (torch.cuda.Stream(device=self.device, priority=pt), torch.cuda.Stream(device=self.device, priority=pv))
+            # (default priorities: a high-priority text stream bought 0.5 % at one GPU and cost 2x under data
+            #  parallelism, where the all-reduce of step i must get CUs while the encoders of step i+1 run)
+            self._enc_streams = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
         return self._enc_bufs[key]
 
     def _encode_text(self, e: dict) -> None:
