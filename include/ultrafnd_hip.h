@@ -245,12 +245,14 @@ int ufnd_gemm_bf16_ln(const void* A, const void* W, const float* bias, const flo
  * (0 = the shape's tile has no statistics epilogue). */
 int ufnd_gemm_bf16_stat_parts(int M, int N, int K);
 
-/* Diagnostics: one launch of tile `tile_cfg` (plain bf16 output, no epilogue extras) built with
- * in-kernel clock stamps.  stamps receives 8 uint64 per block: {s_memtime, s_memrealtime} at kernel
- * entry, after the first K-step has landed, after the K loop, after the last store has drained.
- * tools/gemm_stamps.py turns them into per-phase times and the clock the chip held. */
+/* Diagnostics: one launch of tile `tile_cfg` built with in-kernel clock stamps.  stamps receives 8 uint64 per
+ * block: {s_memtime, s_memrealtime} at kernel entry, after the first K-step has landed, after the K loop, after the
+ * last store has drained.  ln != NULL times the LayerNorm-aware kernel of that tile with those extras (bias,
+ * residual, out_f32 as in ufnd_gemm_bf16_ln; strides = N).  tools/gemm_stamps.py turns the stamps into per-phase
+ * times and the clock the chip held. */
 int ufnd_gemm_bf16_stamps(const void* A, const void* W, void* out_bf16, int M, int N, int K, int tile_cfg,
-                          unsigned long long* stamps, void* stream);
+                          unsigned long long* stamps, const ufnd_gemm_ln* ln, const float* bias, const float* residual,
+                          float* out_f32, void* stream);
 
 /* Split-K form for narrow-N / long-K Linears (BERT output.dense, K = 3072): K is cut into `ksplit`
  * slices, block (tile, s) writes the raw fp32 partial product of slice s to slabs[s] ((M,N), row

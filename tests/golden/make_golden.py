@@ -303,13 +303,18 @@ def init_parity():
     os.chdir(REF)
     from src.models.fusion.cross_modal_transformer import CrossModalTransformer
     from src.models.fusion.deep_truth_classifier import DeepTruthClassifier
-    from src.training.forensic_trainer import TrainConfig
+    from src.training.forensic_trainer import TrainConfig, SimpleGCN
     import dataclasses
+    torch.manual_seed(321)
+    gcn = SimpleGCN(in_dim=416, hid=256, out_dim=128, dropout=0.2)       # as _build_gnn constructs it (:203)
+    gcn_after = float(torch.rand(1))                                      # the RNG position right after the construction
     torch.manual_seed(123)
     fusion = CrossModalTransformer("configs/model_configs/fusion.yaml")
     clf = DeepTruthClassifier("configs/model_configs/classifier.yaml")
     out = {"fusion": {k: [list(v.shape), float(v.double().sum()), float(v.double().abs().sum())] for k, v in fusion.state_dict().items()},
            "clf": {k: [list(v.shape), float(v.double().sum()), float(v.double().abs().sum())] for k, v in clf.state_dict().items()},
+           "gcn": {k: [list(v.shape), float(v.double().sum()), float(v.double().abs().sum())] for k, v in gcn.state_dict().items()},
+           "gcn_rng_after": gcn_after,
            "train_config_fields": [[f.name, repr(f.default) if f.default is not dataclasses.MISSING else None]
                                    for f in dataclasses.fields(TrainConfig)]}
     (HERE / "init_parity.json").write_text(json.dumps(out, indent=0))

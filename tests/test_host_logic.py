@@ -33,6 +33,21 @@ def test_same_seed_gives_the_reference_initial_weights(parity):
     assert sum(p.numel() for p in clf.parameters()) == 539_873
 
 
+def test_simple_gcn_same_seed_init_and_rng_position(parity):
+    """SimpleGCN mirror: the reference's initial weights under the same seed, and the global RNG is left where
+    the reference leaves it (so that everything constructed afterwards also matches)."""
+    from ultrafnd_git_amd.gcn import SimpleGCN, sets_to_csr
+    torch.manual_seed(321)
+    sd = SimpleGCN(in_dim=416, hid=256, out_dim=128, dropout=0.2).state_dict()
+    assert float(torch.rand(1)) == parity["gcn_rng_after"]
+    assert list(sd.keys()) == list(parity["gcn"].keys())
+    for k, (shape, s_, a) in parity["gcn"].items():
+        assert list(sd[k].shape) == shape and abs(float(sd[k].double().sum()) - s_) <= 1e-9 * max(1.0, a), k
+    offs, toks = sets_to_csr([{"b", "a"}, set(), {"a", "c", "a"}])
+    assert offs.tolist() == [0, 2, 2, 4] and len(set(toks[:2].tolist())) == 2 and sorted(toks[2:].tolist()) == toks[2:].tolist()
+    assert len(set(toks.tolist())) == 3          # three distinct phrases, "a" shared
+
+
 def test_train_config_mirrors_the_reference_dataclass(parity):
     from ultrafnd_git_amd.trainer import TrainConfig
     mine = [(f.name, repr(f.default) if f.default is not dataclasses.MISSING else None) for f in dataclasses.fields(TrainConfig)]

@@ -3,7 +3,9 @@
 s_memrealtime at kernel entry, first K-step landed, K loop done, stores drained.  Prints, per tile
 configuration and shape, the median over blocks of each phase in us (100 MHz realtime counter), the
 shader clock held inside the K loop, and the first-start -> last-end span of the whole grid.
-usage: gemm_stamps.py [--cfgs=8,22] [--shapes=bert_qkv,bert_ffn1]"""
+With --ln every tile that has a LayerNorm-aware kernel is also stamped in its two roles: "fold" (LayerNorm of
+the A operand folded in) and "rln" (residual through a LayerNorm + bf16 copy + row statistics out).
+usage: gemm_stamps.py [--cfgs=8,22] [--shapes=bert_qkv,bert_ffn1] [--ln]"""
 import sys
 from pathlib import Path
 
@@ -30,14 +32,38 @@ def main():
         W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).bfloat16()
         ob = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
         print(f"== {name} M={M} N={N} K={K}: median over blocks, us")
+        import ctypes
+        stats = torch.rand(M, 24, 2, device=dev) + 1.0
+        vec = torch.rand(max(N, 3072), device=dev)
+        res = torch.randn(M, N, device=dev)
+        of = torch.empty(M, N, device=dev)
+        sto = torch.empty(M, 24, 2, device=dev)
+        variants = []
         for c, (bm, bn, lay) in TILES.items():
             if N % bn or (only is not None and c not in only):
                 continue
+            variants.append((c, bm, bn, lay, None))
+            if "--ln" in sys.argv and c in (8, 16, 17, 20):
+                variants.append((c, bm, bn, lay + " fold", "fold"))
+                if N // 32 <= 24 and (bn // 2) % 32 == 0:
+                    variants.append((c, bm, bn, lay + " rln", "rln"))
+        for c, bm, bn, lay, mode in variants:
             nblk = -(-M // bm) * (N // bn)
             st = torch.zeros(nblk, 8, dtype=torch.int64, device=dev)
             rows = []
+            ln = None
+            if mode is not None:
+                ln = L.GemmLn()
+                ln.a_eps = ln.r_eps = 1e-5
+                ln.width = 768
+                if mode == "fold":
+                    ln.a_stats, ln.colsum, ln.a_parts = stats.data_ptr(), vec.data_ptr(), 24
+                else:
+                    ln.r_stats, ln.r_gamma, ln.r_beta, ln.r_parts, ln.out_stats = stats.data_ptr(), vec.data_ptr(), vec.data_ptr(), 24, sto.data_ptr()
             for it in range(12):
                 L.check(L.lib().ufnd_gemm_bf16_stamps(A.data_ptr(), W.data_ptr(), ob.data_ptr(), M, N, K, c, st.data_ptr(),
+                                                      ctypes.byref(ln) if ln is not None else None, vec.data_ptr() if ln is not None else None,
+                                                      res.data_ptr() if mode == "rln" else None, of.data_ptr() if mode == "rln" else None,
                                                       L.stream_ptr(A.device)), "stamps")
                 torch.cuda.synchronize()
                 if it >= 4:

@@ -97,7 +97,7 @@ def _declare_encoders(lib: C.CDLL) -> None:
         "ufnd_cast_bf16": [P, P, S, P],
         "ufnd_gemm_bf16": [P] * 6 + [I] * 9 + [P],
         "ufnd_gemm_bf16_ex": [P] * 6 + [I] * 10 + [P],
-        "ufnd_gemm_bf16_stamps": [P, P, P, I, I, I, I, P, P],
+        "ufnd_gemm_bf16_stamps": [P, P, P, I, I, I, I, P, C.POINTER(GemmLn), P, P, P, P],
         "ufnd_layernorm": [P, I, P, P, P, P, I, I, F, P],
         "ufnd_gemm_bf16_splitk": [P, P, P, I, I, I, I, I, I, I, P],
         "ufnd_layernorm_sum": [P, I, P, P, I, P, P, P, P, P, I, I, F, P],

@@ -577,7 +577,7 @@ static const TileCfg kTiles[] = {
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
-// abl: 0 product kernel, 1 / 2 timing ablations, 3 stamps build, 4 LayerNorm-aware kernel
+// abl: 0 product kernel, 1 / 2 timing ablations, 3 stamps build, 4 LayerNorm-aware kernel, 5 LayerNorm-aware stamps build
 static int launch_cfg(int cfg, int abl, GemmArgs& a, hipStream_t stream) {
   const TileCfg& t = kTiles[cfg];
   a.m_tiles = ufnd_cdiv(a.M, t.bm);
@@ -588,6 +588,8 @@ static int launch_cfg(int cfg, int abl, GemmArgs& a, hipStream_t stream) {
     if constexpr (SA_ * BM_ * 128 + SB_ * BN_ * 128 <= 160 * 1024) {                                                \
       if (abl == 4) {                                                                                               \
         if constexpr (LN_ != 0) hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, SA_, SB_, MI_, 0, 0, 1>), grid, block, 0, stream, a); \
+      } else if (abl == 5) {                                                                                        \
+        if constexpr (LN_ != 0) hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, SA_, SB_, MI_, 0, 1, 1>), grid, block, 0, stream, a); \
       } else if (abl == 0) hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, SA_, SB_, MI_, 0, 0>), grid, block, 0, stream, a);      \
       else if (abl == 1) hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, SA_, SB_, MI_, 1, 0>), grid, block, 0, stream, a); \
       else if (abl == 2) hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, SA_, SB_, MI_, 2, 0>), grid, block, 0, stream, a); \
@@ -708,12 +710,21 @@ extern "C" int ufnd_gemm_bf16_ln(const void* A, const void* W, const float* bias
 }
 
 extern "C" int ufnd_gemm_bf16_stamps(const void* A, const void* W, void* out_bf16, int M, int N, int K, int tile_cfg,
-                                     unsigned long long* stamps, void* stream_) {
+                                     unsigned long long* stamps, const ufnd_gemm_ln* ln, const float* bias, const float* residual,
+                                     float* out_f32, void* stream_) {
   UFND_REQUIRE(A && W && out_bf16 && stamps, "gemm_bf16_stamps: null operand");
   UFND_REQUIRE(M >= 1 && N >= 64 && K >= 64 && N % 64 == 0 && K % 64 == 0, "gemm_bf16_stamps: M=%d N=%d K=%d", M, N, K);
   UFND_REQUIRE(tile_cfg >= 0 && tile_cfg < kNumTiles && N % kTiles[tile_cfg].bn == 0, "gemm_bf16_stamps: tile config %d", tile_cfg);
-  GemmArgs a{(const __bf16*)A, (const __bf16*)W, nullptr, nullptr, (__bf16*)out_bf16, nullptr, M, N, K, K, K, 0, N, 0, 0, 0, 0, 1, stamps};
-  int rc = launch_cfg(tile_cfg, 3, a, (hipStream_t)stream_);
+  GemmArgs a{(const __bf16*)A, (const __bf16*)W, bias, residual, (__bf16*)out_bf16, out_f32, M, N, K, K, K, N, N, N, 0, 0, 0, 1, stamps};
+  int abl = 3;
+  if (ln) {      // the LayerNorm-aware kernel of this tile, same extras as ufnd_gemm_bf16_ln (unchecked: diagnostics)
+    UFND_REQUIRE(kTiles[tile_cfg].lnx, "gemm_bf16_stamps: tile %d has no LayerNorm-aware kernel", tile_cfg);
+    a.a_stats = ln->a_stats; a.colsum = ln->colsum; a.r_stats = ln->r_stats; a.r_gamma = ln->r_gamma; a.r_beta = ln->r_beta;
+    a.out_stats = ln->out_stats; a.a_parts = ln->a_parts; a.r_parts = ln->r_parts; a.a_eps = ln->a_eps; a.r_eps = ln->r_eps;
+    a.inv_h = 1.0f / (float)ln->width;
+    abl = 5;
+  }
+  int rc = launch_cfg(tile_cfg, abl, a, (hipStream_t)stream_);
   if (rc != UFND_OK) return rc;
   UFND_CHECK_LAUNCH();
   return UFND_OK;
