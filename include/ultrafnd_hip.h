@@ -167,6 +167,12 @@ int ufnd_classifier_backward(const ufnd_dims* d, const ufnd_clf_params* p, const
 int ufnd_softmax_ce(const float* logits, const int64_t* labels, int B, float* loss_rows, float* d_logits,
                     ufnd_step_state* state, void* stream);
 
+/* nn.CrossEntropyLoss(weight=(w0, w1), label_smoothing=eps), mean reduction (normalised by the sum of the
+ * target-class weights), + its gradient: the criterion of the integrated trainer variant
+ * (src/training/forensic_trainer_integrated.py:154-166).  eps = 0, w = (1, 1) is ufnd_softmax_ce. */
+int ufnd_softmax_ce_weighted(const float* logits, const int64_t* labels, int B, float w0, float w1, float label_smoothing,
+                             float* loss_rows, float* d_logits, ufnd_step_state* state, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * clip_grad_norm_ + AdamW.step over a flat fp32 arena    forensic_trainer.py:292-298,176
  *   grad/param/exp_avg/exp_avg_sq: n floats each (n % 4 == 0, 16-byte aligned).

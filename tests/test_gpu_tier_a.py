@@ -203,3 +203,49 @@ def test_temporal_align_matches_reference():
     assert err <= 2e-6 and np.abs(one - z["out_self"]).max() <= 2e-6 and one.dtype == np.float32
     wide = net.align_batch(t, torch.cat([torch.from_numpy(z["t"]), torch.ones(6, 40)], dim=1))    # Dv > D: truncated
     assert np.abs(wide.cpu().numpy() - T.align(T.seeded_weights(51), t, t).numpy()).max() <= 2e-6
+
+
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("w,eps", [((1.0, 1.0), 0.05), ((0.7, 1.9), 0.0), ((0.6, 1.4), 0.05)])
+def test_weighted_label_smoothed_ce_matches_torch(w, eps):
+    """The integrated variant's criterion (forensic_trainer_integrated.py:154-166): nn.CrossEntropyLoss(weight,
+    label_smoothing) -- loss and d loss / d logits against torch autograd."""
+    from ultrafnd_git_amd import _lib as L
+    from ultrafnd_git_amd.state import StepStateBuffer
+    g = torch.Generator().manual_seed(3)
+    for B in (1, 5, 300):
+        logits = (torch.randn(B, 2, generator=g) * 2).requires_grad_(True)
+        y = torch.randint(0, 2, (B,), generator=g)
+        ref = torch.nn.CrossEntropyLoss(weight=torch.tensor(w), label_smoothing=eps)(logits, y)
+        ref.backward()
+        lg, yd = logits.detach().to(DEV), y.to(DEV)
+        d = torch.empty(B, 2, device=DEV)
+        rows = torch.empty(B, device=DEV)
+        st = StepStateBuffer(torch.device(DEV))
+        L.check(L.lib().ufnd_softmax_ce_weighted(lg.data_ptr(), yd.data_ptr(), B, w[0], w[1], eps, rows.data_ptr(), d.data_ptr(), st.ptr,
+                                                 L.stream_ptr(lg.device)), "ce")
+        assert abs(float(st.read().loss) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+        assert abs(float(rows.sum()) - float(ref)) <= 1e-5
+        assert (d.cpu() - logits.grad).abs().max().item() <= 2e-7 + 1e-5 * logits.grad.abs().max().item()
+
+
+def test_cosine_schedule_and_criterion_options_in_the_trainer():
+    """TrainConfig(label_smoothing, class_weighting, use_cosine): the integrated variant's options on the same step."""
+    import math
+    from ultrafnd_git_amd.trainer import ForensicTrainer, TrainConfig, synthetic_cache
+    cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir="/tmp/ufnd_int_t", batch_size=16, epochs=4, device=DEV, seed=3,
+                      label_smoothing=0.05, class_weighting=True, use_cosine=True, min_lr_scale=0.1)
+    cache = synthetic_cache(80, seed=2)
+    tr = ForensicTrainer(cfg, cache=cache)
+    y = cache["labels"]
+    assert abs(tr._ce_w[0] - 0.5 * len(y) / max(1, (y == 0).sum())) < 1e-9
+    loss, _ = tr._epoch_loop(tr.train_loader, "train")
+    assert math.isfinite(loss)
+    lrs = []
+    for _ in range(4):
+        tr.scheduler.step()
+        lrs.append(tr.scheduler.get_last_lr()[0])
+    want = [2e-5 + (2e-4 - 2e-5) * (1 + math.cos(math.pi * e / 4)) / 2 for e in (1, 2, 3, 4)]
+    assert max(abs(a - b) for a, b in zip(lrs, want)) <= 1e-9

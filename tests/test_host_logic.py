@@ -53,7 +53,8 @@ def test_train_config_mirrors_the_reference_dataclass(parity):
     mine = [(f.name, repr(f.default) if f.default is not dataclasses.MISSING else None) for f in dataclasses.fields(TrainConfig)]
     ref = [tuple(x) for x in parity["train_config_fields"]]
     assert mine[:len(ref)] == ref                 # same fields, order and defaults; additions only at the end
-    assert [n for n, _ in mine[len(ref):]] == ["device", "use_graph", "encode_inline"]
+    assert [n for n, _ in mine[len(ref):]] == ["device", "use_graph", "encode_inline", "label_smoothing", "class_weighting", "use_cosine",
+                                               "min_lr_scale"]
 
 
 def test_arena_layout_keeps_stacked_groups_contiguous_and_aligned():

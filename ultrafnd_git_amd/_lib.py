@@ -81,6 +81,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.ufnd_classifier_backward.argtypes = [C.POINTER(Dims), C.POINTER(ClfParams), C.POINTER(ClfParams), I, I, P, P, P,
                                              I, P, P, P, I]
     lib.ufnd_softmax_ce.argtypes = [P, P, I, P, P, P, P]
+    lib.ufnd_softmax_ce_weighted.argtypes = [P, P, I, C.c_float, C.c_float, C.c_float, P, P, P, P]
+    lib.ufnd_softmax_ce_weighted.restype = I
     lib.ufnd_grad_norm.argtypes = [P, S, P, P, P]
     lib.ufnd_adamw_step.argtypes = [P, P, P, P, S, P, P]
     lib.ufnd_step_advance.argtypes = [P, P]

@@ -610,6 +610,39 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* logits, co
   if (threadIdx.x == 0) st->loss = ((sh[0] + sh[1]) + (sh[2] + sh[3])) / (float)B;
 }
 
+// nn.CrossEntropyLoss(weight=w, label_smoothing=eps), mean reduction (forensic_trainer_integrated.py:166):
+//   loss = sum_i [(1-eps) w[y_i] nll_i(y_i) + eps/2 sum_c w[c] nll_i(c)] / sum_i w[y_i]
+//   dlogits[i][c] = [p_c ((1-eps) w[y_i] + eps/2 (w0 + w1)) - (1-eps) w[y_i] [c == y_i] - eps/2 w[c]] / sum_i w[y_i]
+__global__ __launch_bounds__(256) void softmax_ce_ws_kernel(const float* logits, const int64_t* labels, int B, float w0, float w1,
+                                                            float eps, float* loss_rows, float* dlog, ufnd_step_state* st) {
+  __shared__ float sh[4], shw[4];
+  float part = 0, wsum = 0;
+  for (int r = threadIdx.x; r < B; r += 256) wsum += labels[r] ? w1 : w0;
+  wsum = wave_sum(wsum);
+  if ((threadIdx.x & 63) == 0) shw[threadIdx.x >> 6] = wsum;
+  __syncthreads();
+  const float W = (shw[0] + shw[1]) + (shw[2] + shw[3]);
+  for (int r = threadIdx.x; r < B; r += 256) {
+    const float l0 = logits[r * 2], l1 = logits[r * 2 + 1], mx = fmaxf(l0, l1);
+    const float lse = mx + logf(__expf(l0 - mx) + __expf(l1 - mx));
+    const int y = (int)labels[r];
+    const float wy = y ? w1 : w0;
+    const float n0 = lse - l0, n1 = lse - l1;                       // -log p_c
+    const float lr = (1.0f - eps) * wy * (y ? n1 : n0) + 0.5f * eps * (w0 * n0 + w1 * n1);
+    if (loss_rows) loss_rows[r] = lr / W;
+    part += lr;
+    if (dlog) {
+      const float k = (1.0f - eps) * wy + 0.5f * eps * (w0 + w1);
+      dlog[r * 2] = (__expf(l0 - lse) * k - (y == 0 ? (1.0f - eps) * wy : 0.f) - 0.5f * eps * w0) / W;
+      dlog[r * 2 + 1] = (__expf(l1 - lse) * k - (y == 1 ? (1.0f - eps) * wy : 0.f) - 0.5f * eps * w1) / W;
+    }
+  }
+  part = wave_sum(part);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) st->loss = ((sh[0] + sh[1]) + (sh[2] + sh[3])) / W;
+}
+
 int check_dims(const ufnd_dims* d, int B) {
   UFND_REQUIRE(d, "dims is null");
   UFND_REQUIRE(d->hidden == 256 || d->hidden == 512 || d->hidden == 1024, "hidden=%d: supported 256/512/1024", d->hidden);
@@ -908,6 +941,17 @@ extern "C" int ufnd_classifier_backward(const ufnd_dims* d, const ufnd_clf_param
     TRY(launch_nn(&n, 1, state, stream));
   }
   if (join) fj.join(7);
+  return UFND_OK;
+}
+
+extern "C" int ufnd_softmax_ce_weighted(const float* logits, const int64_t* labels, int B, float w0, float w1, float label_smoothing,
+                                        float* loss_rows, float* d_logits, ufnd_step_state* state, void* stream_) {
+  UFND_REQUIRE(logits && labels && state && B >= 1, "softmax_ce_weighted: null argument");
+  UFND_REQUIRE(w0 > 0.0f && w1 > 0.0f && label_smoothing >= 0.0f && label_smoothing < 1.0f, "softmax_ce_weighted: w=(%g,%g) eps=%g", w0, w1,
+               label_smoothing);
+  hipLaunchKernelGGL(softmax_ce_ws_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream_, logits, labels, B, w0, w1, label_smoothing,
+                     loss_rows, d_logits, state);
+  UFND_CHECK_LAUNCH();
   return UFND_OK;
 }
 

@@ -71,3 +71,23 @@ class StepLR:
 
     def get_last_lr(self):
         return [self.optimizer.param_groups[0]["lr"]]
+
+
+class CosineAnnealingLR:
+    """torch.optim.lr_scheduler.CosineAnnealingLR(optim, T_max, eta_min) for FusedAdamW (closed form), the
+    integrated variant's schedule (forensic_trainer_integrated.py:151-155: T_max = epochs, eta_min = lr * min_lr_scale)."""
+
+    def __init__(self, optim: FusedAdamW, T_max: int, eta_min: float = 0.0):
+        import math
+        self._math = math
+        self.optim, self.T_max, self.eta_min = optim, max(1, int(T_max)), float(eta_min)
+        self.base_lr = optim.param_groups[0]["initial_lr"]
+        self.last_epoch = 0
+
+    def get_last_lr(self):
+        return [self.optim.param_groups[0]["lr"]]
+
+    def step(self) -> None:
+        self.last_epoch += 1
+        lr = self.eta_min + (self.base_lr - self.eta_min) * (1 + self._math.cos(self._math.pi * self.last_epoch / self.T_max)) / 2
+        self.optim.set_lr(lr)

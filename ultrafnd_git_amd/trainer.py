@@ -37,7 +37,7 @@ from .classifier import DeepTruthClassifier
 from .dp import GradReducer, gather_rows, shard_indices, world_info
 from .fusion import CrossModalTransformer
 from .metrics import aggregate_epoch_metrics, pretty_print
-from .optim import FusedAdamW, StepLR
+from .optim import CosineAnnealingLR, FusedAdamW, StepLR
 
 FEATS = ("text_features", "audio_features", "visual_features", "temporal_features")
 _CACHE_KEY = {"text_features": "text", "audio_features": "audio", "visual_features": "visual",
@@ -65,6 +65,11 @@ class TrainConfig:
     device: str = "cuda"
     use_graph: bool = True        # replay the step from a captured hipGraph
     encode_inline: bool = False   # run the native text / visual encoders inside the step
+    # criterion / schedule of the integrated variant (forensic_trainer_integrated.py:30-46,151-166); defaults = the main trainer
+    label_smoothing: float = 0.0
+    class_weighting: bool = False  # CE weights 0.5 * total / count(class) from the cache's labels
+    use_cosine: bool = False       # CosineAnnealingLR(T_max = epochs, eta_min = lr * min_lr_scale) instead of StepLR(3, 0.7)
+    min_lr_scale: float = 0.1
 
 
 class CachedTensorDataset(torch.utils.data.Dataset):
@@ -190,7 +195,17 @@ class ForensicTrainer:
         self.optim = FusedAdamW(self.arena, lr=cfg.lr, weight_decay=cfg.weight_decay,
                                 max_norm=cfg.grad_clip if cfg.grad_clip and cfg.grad_clip > 0 else 0.0,
                                 seed=cfg.seed + 1000 * self.rank, grad_scale=self.reducer.grad_scale)
-        self.scheduler = StepLR(self.optim, step_size=3, gamma=0.7)
+        if cfg.use_cosine:
+            self.scheduler = CosineAnnealingLR(self.optim, T_max=cfg.epochs, eta_min=cfg.lr * cfg.min_lr_scale)
+        else:
+            self.scheduler = StepLR(self.optim, step_size=3, gamma=0.7)
+        # criterion: plain mean CE (forensic_trainer.py:287) unless the integrated variant's options are set
+        self._ce_w = (1.0, 1.0)
+        if cfg.class_weighting:
+            y = np.asarray(self.cache["labels"])
+            pos, neg = float((y == 1).sum()), float((y == 0).sum())
+            total = max(1.0, pos + neg)
+            self._ce_w = (0.5 * total / max(1.0, neg), 0.5 * total / max(1.0, pos))
         self.text_encoder, self.visual_encoder = text_encoder, visual_encoder
         self.temporal_net = temporal_net    # optional TemporalSyncNet: temporal = align(text, visual) inside the step
         if cfg.encode_inline and (text_encoder is None or visual_encoder is None):
@@ -283,8 +298,13 @@ class ForensicTrainer:
         L.check(lib.ufnd_classifier_forward(C.byref(d), C.byref(self.clf.param_table()), b["xin"], b["ldx"],
                                             b["aux"].data_ptr(), B, int(train), b["cws"].data_ptr(), b["logits"].data_ptr(),
                                             b["probs"].data_ptr(), st, s), "ufnd_classifier_forward")
-        L.check(lib.ufnd_softmax_ce(b["logits"].data_ptr(), b["label"].data_ptr(), B, None,
-                                    b["dlogits"].data_ptr() if with_loss_grad else None, st, s), "ufnd_softmax_ce")
+        if self.cfg.label_smoothing > 0.0 or self.cfg.class_weighting:
+            L.check(lib.ufnd_softmax_ce_weighted(b["logits"].data_ptr(), b["label"].data_ptr(), B, self._ce_w[0], self._ce_w[1],
+                                                 float(self.cfg.label_smoothing), None,
+                                                 b["dlogits"].data_ptr() if with_loss_grad else None, st, s), "ufnd_softmax_ce_weighted")
+        else:
+            L.check(lib.ufnd_softmax_ce(b["logits"].data_ptr(), b["label"].data_ptr(), B, None,
+                                        b["dlogits"].data_ptr() if with_loss_grad else None, st, s), "ufnd_softmax_ce")
 
     def _enqueue_backward(self, b: dict, B: int) -> None:
         lib, s, st = L.lib(), L.stream_ptr(self.device), self.optim.state.ptr
