@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1]: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--seq-len", type=int, default=128, help="text length (BASELINE configs[3]: 512 with --batch 128)")
+    ap.add_argument("--frames", type=int, default=1, help="frames per sample (BASELINE configs[4]: 8 with --batch 8 per GPU)")
     ap.add_argument("--no-fold-ln", action="store_true", help="one LayerNorm kernel per LayerNorm instead of folding them into the GEMM epilogues")
     ap.add_argument("--head-only", action="store_true",
                     help="secondary measurement: the reference's actual training mode (cached features, no encoders in the step)")
@@ -144,6 +146,8 @@ def main():
                           "algorithmic_MB_per_step": round(11 * 4 * P / 1e6, 1),
                           "hbm_GBps_algorithmic": round(11 * 4 * P / (dt / args.steps) / 1e9, 1)}))
         return
+    global SEQ_LEN, FRAMES
+    SEQ_LEN, FRAMES = args.seq_len, args.frames       # (defaults = the headline configuration, BASELINE configs[1])
     tenc = BertTextEncoder(fold_ln=not args.no_fold_ln).to(dev)            # BERT-base geometry, random init (no checkpoints offline)
     venc = ClipVisualEncoder(fold_ln=not args.no_fold_ln).to(dev)          # CLIP ViT-B/32 geometry, random init
     cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir="/tmp/ufnd_bench", batch_size=B, device=str(dev),
@@ -202,7 +206,8 @@ def main():
             "metric": "train-step samples/sec (FakeSV batch, seq128+224^2)", "value": round(value, 2), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: full Ultrafnd step (BERT-base L=128 fwd + ViT-B/32 224^2 fwd, frozen; "
+            "config": {"workload": ("BASELINE configs[1]" if (SEQ_LEN, FRAMES, B) == (128, 1, 32) else "variant of BASELINE configs[1]") +
+                                   f": full Ultrafnd step (BERT-base L={SEQ_LEN} fwd + {FRAMES} x ViT-B/32 224^2 fwd, frozen; "
                                    "fusion+classifier fwd/bwd, clip, AdamW)", "per_gpu_batch": B, "global_batch": world * B,
                        "seq_len": SEQ_LEN, "frames": FRAMES, "image": IMAGE, "parallelism": f"dp{world}",
                        "encoder_dtype": "bf16 operands / fp32 accumulate", "head_dtype": "fp32", "hip_graph": not args.no_graph,
