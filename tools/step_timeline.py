@@ -25,6 +25,11 @@ def main():
     ap.add_argument("--no-fold-ln", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
+    import os
+    if "RANK" in os.environ:          # under torchrun: the data-parallel path (UFND_FORCE_REDUCE=1 runs the collective at world 1)
+        import torch.distributed as dist
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", device_id=dev)
     B = args.batch
     tenc = BertTextEncoder(fold_ln=not args.no_fold_ln).to(dev)
     venc = ClipVisualEncoder(fold_ln=not args.no_fold_ln).to(dev)
@@ -71,7 +76,7 @@ def main():
     print(f"wall {wall * 1e3:.3f} ms/step; host enqueue median {statistics.median(host) * 1e3:.3f} ms/step")
     print("event offsets from the step's first compute-stream event, us (median):")
     print("  (text0/vis0..text1/vis1 = the encoder graphs of the NEXT batch, launched behind this step's head)")
-    for tag in ("step0", "head0", "head1", "text0", "text1", "vis0", "vis1", "opt1", "next step0"):
+    for tag in ("step0", "head0", "head1", "reduce1", "text0", "text1", "vis0", "vis1", "opt1", "next step0"):
         if tag in rows:
             print(f"   {tag:12s} {statistics.median(rows[tag]):9.1f}")
 

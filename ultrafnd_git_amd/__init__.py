@@ -1,0 +1,1 @@
+"""MI355X-native text+vision fusion train step of Ultrafnd."""
