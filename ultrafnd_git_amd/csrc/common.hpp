@@ -76,6 +76,15 @@ __device__ __forceinline__ float gelu_fast_f(float x) {
   return __fmaf_rn(h, copysignf(erf_abs, x), h);
 }
 
+// butterfly partner inside a quad (lanes 4k..4k+3) by DPP quad_perm: no LDS round trip (a __shfl_xor compiles to
+// ds_bpermute, ~100 cycles of dependent latency each)
+__device__ __forceinline__ float quad_xor1(float v) {       // lane ^ 1: quad_perm [1,0,3,2]
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float quad_xor2(float v) {       // lane ^ 2: quad_perm [2,3,0,1]
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

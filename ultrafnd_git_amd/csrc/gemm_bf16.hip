@@ -241,19 +241,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
       }
       float sm, sq;
       if constexpr (TPR == 4) {        // lane sub holds group sub
-        sm = gs[0] + __shfl_xor(gs[0], 1, 64);
-        sq = gq[0] + __shfl_xor(gq[0], 1, 64);
-        sm += __shfl_xor(sm, 2, 64);
-        sq += __shfl_xor(sq, 2, 64);
+        sm = gs[0] + quad_xor1(gs[0]);
+        sq = gq[0] + quad_xor1(gq[0]);
+        sm += quad_xor2(sm);
+        sq += quad_xor2(sq);
       } else {                         // lane sub holds groups sub and sub + 2
-        const float s01 = gs[0] + __shfl_xor(gs[0], 1, 64), s23 = gs[1] + __shfl_xor(gs[1], 1, 64);
-        const float q01 = gq[0] + __shfl_xor(gq[0], 1, 64), q23 = gq[1] + __shfl_xor(gq[1], 1, 64);
+        const float s01 = gs[0] + quad_xor1(gs[0]), s23 = gs[1] + quad_xor1(gs[1]);
+        const float q01 = gq[0] + quad_xor1(gq[0]), q23 = gq[1] + quad_xor1(gq[1]);
         sm = s01 + s23;
         sq = q01 + q23;
       }
       const float mean = __fmul_rn(sm, a.inv_h);
       const float var = fmaxf(__fmaf_rn(-mean, mean, __fmul_rn(sq, a.inv_h)), 0.f);
-      if (threadIdx.x % TPR == 0) st_lds[threadIdx.x / TPR] = f32x2{mean, __frcp_rn(__fsqrt_rn(__fadd_rn(var, a.a_stats ? a.a_eps : a.r_eps)))};
+      if (threadIdx.x % TPR == 0) st_lds[threadIdx.x / TPR] = f32x2{mean, __builtin_amdgcn_rsqf(__fadd_rn(var, a.a_stats ? a.a_eps : a.r_eps))};   // v_rsq_f32 (1 ulp, the same instruction in every tile shape)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   }
@@ -465,10 +465,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
               float sm = 0.f, sq = 0.f;
 #pragma unroll
               for (int q = 0; q < 8; ++q) { sm = __fadd_rn(sm, v[q]); sq = __fmaf_rn(v[q], v[q], sq); }
-              sm += __shfl_xor(sm, 1, 64);
-              sq += __shfl_xor(sq, 1, 64);
-              sm += __shfl_xor(sm, 2, 64);
-              sq += __shfl_xor(sq, 2, 64);
+              sm += quad_xor1(sm);
+              sq += quad_xor1(sq);
+              sm += quad_xor2(sm);
+              sq += quad_xor2(sq);
               if (live && (id & 3) == 0)
                 *reinterpret_cast<f32x2*>(a.out_stats + ((size_t)row * (a.N >> 5) + (col >> 5)) * 2) = f32x2{sm, sq};
             }
