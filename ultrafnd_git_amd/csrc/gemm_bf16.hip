@@ -560,14 +560,8 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* src, __bf16
   X(23, 256, 256, 4, 2, 3, 2, 16, 0)  /* 160 KiB */                                                           \
   X(24, 128, 192, 4, 2, 4, 4, 16, 0)  /* 160 KiB */                                                           \
   X(25, 128, 256, 4, 2, 3, 3, 16, 0)  /* 144 KiB (8 waves, wave tile 32x128) */                               \
-  X(26, 256, 192, 4, 2, 2, 2, 32, 0)  /* 32x32x16 MFMA forms */                                              \
-  X(27, 256, 192, 4, 2, 3, 2, 32, 0)                                                                      \
-  X(28, 128, 128, 4, 2, 3, 3, 32, 0)                                                                      \
-  X(29, 128, 192, 4, 2, 3, 3, 32, 0)                                                                      \
-  X(30, 256, 256, 4, 2, 3, 2, 32, 0)                                                                      \
-  X(31, 128, 64, 4, 2, 4, 4, 32, 0)                                                                       \
-  X(32, 256, 128, 4, 2, 3, 3, 32, 0)                                                                      \
-  X(33, 128, 64, 2, 2, 3, 3, 32, 0)   /* 2 blocks/CU */
+  X(26, 256, 192, 4, 2, 2, 2, 32, 0)  /* 32x32x16 MFMA form (measured 2-4 % slower than 16x16x32 on every shape) */ \
+  X(27, 128, 128, 4, 2, 3, 3, 32, 0)
 
 struct TileCfg { int bm, bn, threads, wn, lnx; };
 static const TileCfg kTiles[] = {
