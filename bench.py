@@ -116,7 +116,8 @@ def main():
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ      # started by torch.distributed.run
     if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        from ultrafnd_git_amd.dp import init_process_group
+        init_process_group(dev)
     if args.gpus != world and rank == 0:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: using {world}", file=sys.stderr)
 

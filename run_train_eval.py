@@ -48,7 +48,8 @@ def main():
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        from ultrafnd_git_amd.dp import init_process_group
+        init_process_group(torch.device("cuda", local))
     rank = int(os.environ.get("RANK", "0"))
     out_dir = Path(args.out_dir).expanduser()
     out_dir.mkdir(parents=True, exist_ok=True)

@@ -23,6 +23,21 @@ import torch
 import torch.distributed as dist
 
 
+def init_process_group(device: torch.device) -> None:
+    """`nccl` (= RCCL) process group whose internal stream is HIGH priority: the gradient exchange sits on the serial
+    head -> exchange -> optimizer chain while two encoder graphs keep every CU busy; at normal priority its
+    kernels queue for CUs behind whole-CU GEMM blocks."""
+    opts = None
+    try:
+        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+    except Exception:          # (older torch without the option: default priority)
+        opts = None
+    if opts is not None:
+        dist.init_process_group("nccl", device_id=device, pg_options=opts)
+    else:
+        dist.init_process_group("nccl", device_id=device)
+
+
 def world_info(group=None):
     if dist.is_available() and dist.is_initialized():
         return dist.get_world_size(group), dist.get_rank(group)
