@@ -96,7 +96,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
   constexpr int MT = TM / MI, NT = TN / MI;      // MFMA tiles per wave
   constexpr int ASLOT = BM * 128, BSLOT = BN * 128;
   constexpr int DA = STA - 1, DB = STB - 1;      // K-steps of lookahead per operand
-  constexpr int PWA = BM / 8 / NW, PWB = BN / 8 / NW;   // DMA wave-instructions per wave per K-step
+  // DMA wave-instructions per wave per K-step.  Where the W pieces do not divide evenly over the waves (BN = 144:
+  // 18 pieces, 8 waves) every wave still issues PWB pieces and the surplus ones re-load pieces 0.. (the same bytes to
+  // the same LDS address): the counted vmcnt stays uniform at the price of a few redundant 1-KiB loads.
+  constexpr int APIECES = BM / 8, BPIECES = BN / 8;
+  constexpr int PWA = APIECES / NW, PWB = (BPIECES + NW - 1) / NW;
   constexpr int WAITN = PWA * (DA - 1 > 0 ? DA - 1 : 0) + PWB * (DB - 1 > 0 ? DB - 1 : 0);
   constexpr int CP = TN + 4;                     // fp32 C-staging pitch (floats), MI rows per wave
   constexpr int CBYTES = NW * MI * CP * 4;
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
   constexpr int STAT_OFF = (RING > CBYTES) ? RING : CBYTES;           // LNX: {mean, rstd} per tile row, behind the ring
   constexpr int SMEM = STAT_OFF + (LNX ? BM * 8 : 0);
   static_assert(SMEM <= 160 * 1024, "LDS budget");
-  static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0 && TM % MI == 0 && TN % MI == 0, "tile split");
+  static_assert(APIECES % NW == 0 && TM % MI == 0 && TN % MI == 0, "tile split");
   static_assert(STB >= 2 && (STA == STB || STA == STB + 1), "ring depths");
   static_assert(WAITN <= 63, "vmcnt range");
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
@@ -158,7 +162,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     const int k0 = kbase + t * BK;
 #pragma unroll
     for (int ii = 0; ii < PWB; ++ii) {
-      const int p = wave + NW * ii;
+      int p = wave + NW * ii;
+      if constexpr (BPIECES % NW != 0) p = p < BPIECES ? p : p - BPIECES;
       const int r = 8 * p + prow;
       const int c = ppos ^ ((r >> 1) & 7);
       int gr = n0 + r;
@@ -561,7 +566,8 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* src, __bf16
   X(24, 128, 192, 4, 2, 4, 4, 16, 0)  /* 160 KiB */                                                           \
   X(25, 128, 256, 4, 2, 3, 3, 16, 0)  /* 144 KiB (8 waves, wave tile 32x128) */                               \
   X(26, 256, 192, 4, 2, 2, 2, 32, 0)  /* 32x32x16 MFMA form (measured 2-4 % slower than 16x16x32 on every shape) */ \
-  X(27, 128, 128, 4, 2, 3, 3, 32, 0)
+  X(27, 128, 128, 4, 2, 3, 3, 32, 0)                                                                    \
+  X(28, 256, 144, 8, 1, 2, 2, 16, 1)  /* 100 KiB: N=2304 -> 16 x 16 = 256 tiles (wave tile 32x144; W pieces dealt unevenly) */
 
 struct TileCfg { int bm, bn, threads, wn, lnx; };
 static const TileCfg kTiles[] = {
@@ -606,6 +612,9 @@ static int auto_cfg(int M, int N, int K) {
   static const int forced = [] { const char* e = getenv("UFND_GEMM_FORCE_CFG"); return e ? atoi(e) : -1; }();   // experiments only
   if (forced >= 0 && forced < kNumTiles && N % kTiles[forced].bn == 0) return forced;
   auto tiles = [&](int cfg) { return (long long)ufnd_cdiv(M, kTiles[cfg].bm) * (N / kTiles[cfg].bn); };
+  // (256x144 gives BERT QKV 256 tiles instead of 192 and is 8 % faster alone -- 17.2 vs 18.8 us -- but the step got
+  //  4 % SLOWER with it: the 64 CUs the 192-tile launch leaves free are where the other encoder's and the head's
+  //  kernels run meanwhile.  Tile 28 stays in the table for the sweep; it is not selected.)
   if (N % 192 == 0 && tiles(8) >= 160) return 8;      // 256x192: BERT QKV (192 tiles) / FFN1 (256)
   if (N >= 2048) {                                     // wide N, fewer rows (ViT QKV / FFN1): 32-row wave tiles
     if (N % 192 == 0 && N >= 3072) return 17;          //   128x192
