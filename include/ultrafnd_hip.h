@@ -285,6 +285,20 @@ int ufnd_layernorm(const float* x, int ldx, const float* gamma, const float* bet
 int ufnd_attention_bf16(const void* qkv, const int32_t* key_mask, void* ctx, int B, int L, int heads,
                         void* stream);
 
+/* Packed (un-padded) forms: the tokens a padding mask keeps, concatenated over the batch (T rows; sequence b owns
+ * rows cu_seqlens[b] .. cu_seqlens[b+1]; pos_ids (T) = each token's position in its sequence).  HF BertModel computes
+ * the padded positions too (text_blocks.py:71-79 pads every string to max_length) and the pooling then ignores them
+ * (:82-86); skipping them changes no kept value -- with prefix masks the features are bit-identical.
+ *   ufnd_bert_embed_packed     LayerNorm(word[ids] + position[pos_ids] + token_type[0]) for T packed tokens
+ *   ufnd_attention_bf16_varlen per-sequence attention over the packed fused-QKV rows (every key valid)
+ *   ufnd_meanpool_l2_packed    mean over each sequence's rows, then v / (||v|| + 1e-9) */
+int ufnd_bert_embed_packed(const int64_t* ids, const int32_t* pos_ids, const float* word, const float* pos, const float* type0,
+                           const float* gamma, const float* beta, void* x_bf16, float* x_f32, int T, int max_pos, int H,
+                           int vocab, float eps, void* stream);
+int ufnd_attention_bf16_varlen(const void* qkv, const int32_t* cu_seqlens, void* ctx, int B, int max_len, int heads, void* stream);
+int ufnd_meanpool_l2_packed(const float* hidden, const int32_t* cu_seqlens, const int32_t* pos_ids, float* out, int B, int H,
+                            void* stream);
+
 /* BertEmbeddings: LayerNorm(word[ids] + position[0..L) + token_type[0]).  Tables fp32.
  *   ids (B,L) int64 in [0,vocab).  Outputs (B*L,H): bf16 and fp32. */
 int ufnd_bert_embed(const int64_t* ids, const float* word, const float* pos, const float* type0, const float* gamma,

@@ -357,3 +357,48 @@ def test_end_to_end_logit_error():
     perr = (co["probs"].cpu() - ref["probs"]).abs().max().item()
     print(f"end-to-end logits max-abs-err {err:.3e} (probs {perr:.3e}); |logits| max {ref['logits'].abs().max().item():.3f}")
     assert err <= 1e-3, err
+
+
+@pytest.mark.parametrize("fold", [True, False])
+def test_unpadded_text_encoder_is_bit_identical_for_prefix_masks(fold):
+    """BertTextEncoder(..., unpad=True) computes only the tokens the padding mask keeps (packed rows, per-sequence
+    attention).  Padded positions never reach the pooling, so with prefix masks every feature is bit-identical to the
+    padded run; arbitrary masks regroup the keys and agree to rounding; an all-masked row gives the zero vector."""
+    from oracle import encoders_ref as E
+    from ultrafnd_git_amd.encoders import BertTextEncoder
+    wt = E.seeded_weights(E.bert_shapes(layers=3, vocab=1000), 71)
+    enc = BertTextEncoder(layers=3, vocab_size=1000, fold_ln=fold)
+    enc.load_state_dict(wt)
+    enc = enc.to(DEV)
+    g = torch.Generator().manual_seed(9)
+    B, Lq = 9, 256                                    # the reference pads every string to max_length = 256
+    ids = torch.randint(0, 1000, (B, Lq), generator=g)
+    lens = torch.tensor([256, 1, 17, 64, 65, 128, 200, 31, 5])
+    mask = (torch.arange(Lq)[None, :] < lens[:, None]).int()
+    dense = enc(ids, mask).clone()
+    packed = enc(ids, mask, unpad=True).clone()
+    assert torch.equal(dense, packed)
+    ref = E.text_features(wt, ids, mask)
+    assert (packed.cpu() - ref).abs().max().item() <= 4e-3
+    # a hole in the middle of a mask and an empty row
+    mask2 = mask.clone()
+    mask2[3, 10:20] = 0
+    mask2[7] = 0
+    d2, p2 = enc(ids, mask2).clone(), enc(ids, mask2, unpad=True).clone()
+    assert (d2 - p2).abs().max().item() <= 2e-3
+    assert torch.equal(p2[7], torch.zeros_like(p2[7])) and torch.equal(d2[[0, 1, 2, 4, 5, 6, 8]], p2[[0, 1, 2, 4, 5, 6, 8]])
+
+
+def test_encode_fields_unpadded_equals_padded():
+    from ultrafnd_git_amd.encoders import BertTextEncoder
+    enc = BertTextEncoder(layers=2, vocab_size=500).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    N, Mx, Lq = 6, 12, 64
+    ids = torch.randint(0, 500, (N, Mx, Lq), generator=g)
+    lens = torch.randint(1, 30, (N, Mx), generator=g)
+    mask = (torch.arange(Lq)[None, None, :] < lens[..., None]).int()
+    valid = (torch.rand(N, Mx, generator=g) < 0.7).int()
+    valid[2] = 0
+    a = enc.encode_fields(ids, mask, valid, unpad=False).clone()
+    b = enc.encode_fields(ids, mask, valid, unpad=True).clone()
+    assert torch.equal(a, b) and torch.equal(a[2], torch.zeros_like(a[2]))

@@ -106,6 +106,9 @@ def _declare_encoders(lib: C.CDLL) -> None:
         "ufnd_attention_bf16": [P, P, P, I, I, I, P],
         "ufnd_bert_embed": [P] * 8 + [I, I, I, I, F, P],
         "ufnd_masked_meanpool_l2": [P, P, P, I, I, I, P],
+        "ufnd_bert_embed_packed": [P] * 9 + [I, I, I, I, F, P],
+        "ufnd_attention_bf16_varlen": [P, P, P, I, I, I, P],
+        "ufnd_meanpool_l2_packed": [P, P, P, P, I, I, P],
         "ufnd_vit_patchify": [P, P, I, I, I, P],
         "ufnd_vit_assemble": [P] * 8 + [I, I, I, F, P],
         "ufnd_gemm_bf16_ln": [P] * 6 + [I] * 9 + [C.POINTER(GemmLn), P],

@@ -30,7 +30,7 @@ __device__ __forceinline__ bf16x8 k_frag(const char* tile, int row, int chunk) {
 // KB = keys per block (64: ~216 registers -> two workgroups per CU; 128: fewer softmax rescales)
 template <int KB>
 __global__ __launch_bounds__(256) void attention_kernel(const __bf16* qkv, const int32_t* mask, __bf16* ctx, int L,
-                                                        int heads, float scale_log2e) {
+                                                        int heads, float scale_log2e, const int32_t* cu) {
   __shared__ __attribute__((aligned(16))) char ks[KB * 128];
   __shared__ __attribute__((aligned(16))) char vs[KB * 128];
   __shared__ __attribute__((aligned(16))) float kbias[KB];
@@ -38,7 +38,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const __bf16* qkv, const
   const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int H = heads * 64, ld = 3 * H;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, fr = lane & 15, g = lane >> 4;
-  const size_t tok0 = (size_t)b * L;
+  size_t tok0 = (size_t)b * L;
+  if (cu) {              // packed (un-padded) sequences: rows cu[b] .. cu[b+1], every key valid
+    tok0 = (size_t)cu[b];
+    L = cu[b + 1] - cu[b];
+    if (qb * QB >= L) return;      // (block-uniform, before any barrier)
+  }
 
   // Q fragments (B operand): lane (query fr, g) holds Q[query][8g + 32kk .. +7]
   bf16x8 qf[2][2];
@@ -183,7 +188,20 @@ extern "C" int ufnd_attention_bf16(const void* qkv, const int32_t* key_mask, voi
   UFND_REQUIRE(B <= 65535, "attention: B too large for grid.z");
   const float scale_log2e = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) * log2(e)
   hipLaunchKernelGGL(attention_kernel<64>, dim3(ufnd_cdiv(L, QB), heads, B), dim3(256), 0, (hipStream_t)stream_,
-                     (const __bf16*)qkv, key_mask, (__bf16*)ctx, L, heads, scale_log2e);
+                     (const __bf16*)qkv, key_mask, (__bf16*)ctx, L, heads, scale_log2e, (const int32_t*)nullptr);
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}
+
+extern "C" int ufnd_attention_bf16_varlen(const void* qkv, const int32_t* cu_seqlens, void* ctx, int B, int max_len, int heads,
+                                          void* stream_) {
+  UFND_REQUIRE(qkv && ctx && cu_seqlens, "attention_varlen: null operand");
+  UFND_REQUIRE(B >= 1 && B <= 65535 && max_len >= 1 && max_len <= 4096 && heads >= 1 && heads <= 64, "attention_varlen: B=%d max_len=%d heads=%d",
+               B, max_len, heads);
+  UFND_REQUIRE(ufnd_aligned(qkv, 16) && ufnd_aligned(ctx, 16), "attention_varlen: 16-B alignment required");
+  const float scale_log2e = 0.125f * 1.44269504088896340736f;
+  hipLaunchKernelGGL(attention_kernel<64>, dim3(ufnd_cdiv(max_len, QB), heads, B), dim3(256), 0, (hipStream_t)stream_,
+                     (const __bf16*)qkv, (const int32_t*)nullptr, (__bf16*)ctx, max_len, heads, scale_log2e, cu_seqlens);
   UFND_CHECK_LAUNCH();
   return UFND_OK;
 }

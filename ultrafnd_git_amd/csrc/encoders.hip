@@ -101,13 +101,14 @@ template <int NI>
 __global__ __launch_bounds__(256) void bert_embed_kernel(const int64_t* ids, const float* word, const float* pos,
                                                          const float* type0, const float* gamma, const float* beta,
                                                          __bf16* ob, float* of, int M, int L, int H, int vocab,
-                                                         float eps) {
+                                                         float eps, const int32_t* pos_ids) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   long long id = ids[row];
   id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // never read outside the table
-  const int l = row % L;
+  int l = pos_ids ? pos_ids[row] : row % L;         // packed (un-padded) rows carry their position
+  l = l < 0 ? 0 : (l >= L ? L - 1 : l);
   f32x4 v[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
@@ -129,6 +130,31 @@ __global__ __launch_bounds__(256) void meanpool_kernel(const float* hidden, cons
   for (int l = grp; l < L; l += 4) {
     if (mask[(size_t)b * L + l] != 0) {
       acc += ld4(hidden + ((size_t)b * L + l) * H + col);
+      cnt += 1.0f;
+    }
+  }
+  part[grp][lane] = acc;
+  if (lane == 0) cnts[grp] = cnt;
+  __syncthreads();
+  if (grp == 0) {
+    const f32x4 s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    const float denom = fmaxf((cnts[0] + cnts[1]) + (cnts[2] + cnts[3]), 1e-6f);
+    *reinterpret_cast<f32x4*>(out + (size_t)b * H + col) = s / denom;
+  }
+}
+// the same reduction over a PACKED sequence (rows cu[b] .. cu[b+1]): a token joins the group its original position
+// selects and groups add in token order, so the sum is bit-identical to the padded kernel's
+__global__ __launch_bounds__(256) void meanpool_packed_kernel(const float* hidden, const int32_t* cu, const int32_t* pos_ids, float* out,
+                                                              int H) {
+  __shared__ f32x4 part[4][64];
+  __shared__ float cnts[4];
+  const int b = blockIdx.y, col = blockIdx.x * 256 + 4 * (threadIdx.x & 63), grp = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r0 = cu[b], r1 = cu[b + 1];
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float cnt = 0.0f;
+  for (int r = r0; r < r1; ++r) {
+    if ((pos_ids[r] & 3) == grp) {
+      acc += ld4(hidden + (size_t)r * H + col);
       cnt += 1.0f;
     }
   }
@@ -302,7 +328,19 @@ extern "C" int ufnd_bert_embed(const int64_t* ids, const float* word, const floa
   UFND_REQUIRE(ufnd_aligned(word, 16) && ufnd_aligned(pos, 16) && ufnd_aligned(type0, 16), "bert_embed: alignment");
   const int M = B * L;
   NI_LAUNCH(H, bert_embed_kernel, dim3(ufnd_cdiv(M, 4)), (hipStream_t)stream_, ids, word, pos, type0, gamma, beta,
-            (__bf16*)x_bf16, x_f32, M, L, H, vocab, eps);
+            (__bf16*)x_bf16, x_f32, M, L, H, vocab, eps, (const int32_t*)nullptr);
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}
+
+extern "C" int ufnd_bert_embed_packed(const int64_t* ids, const int32_t* pos_ids, const float* word, const float* pos,
+                                      const float* type0, const float* gamma, const float* beta, void* x_bf16, float* x_f32,
+                                      int T, int max_pos, int H, int vocab, float eps, void* stream_) {
+  UFND_REQUIRE(ids && pos_ids && word && pos && type0 && gamma && beta && (x_bf16 || x_f32), "bert_embed_packed: null argument");
+  UFND_REQUIRE(h_ok(H) && T >= 1 && max_pos >= 1 && vocab >= 1, "bert_embed_packed: T=%d H=%d vocab=%d", T, H, vocab);
+  UFND_REQUIRE(ufnd_aligned(word, 16) && ufnd_aligned(pos, 16) && ufnd_aligned(type0, 16), "bert_embed_packed: alignment");
+  NI_LAUNCH(H, bert_embed_kernel, dim3(ufnd_cdiv(T, 4)), (hipStream_t)stream_, ids, word, pos, type0, gamma, beta,
+            (__bf16*)x_bf16, x_f32, T, max_pos, H, vocab, eps, pos_ids);
   UFND_CHECK_LAUNCH();
   return UFND_OK;
 }
@@ -312,6 +350,17 @@ extern "C" int ufnd_masked_meanpool_l2(const float* hidden, const int32_t* mask,
   UFND_REQUIRE(hidden && mask && out && B >= 1 && L >= 1, "meanpool: null argument");
   UFND_REQUIRE(H >= 256 && H % 256 == 0 && ufnd_aligned(hidden, 16) && ufnd_aligned(out, 16), "meanpool: H=%d (multiple of 256)", H);
   hipLaunchKernelGGL(meanpool_kernel, dim3(H / 256, B), dim3(256), 0, (hipStream_t)stream_, hidden, mask, out, L, H);
+  UFND_CHECK_LAUNCH();
+  hipLaunchKernelGGL(l2norm_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream_, out, H);
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}
+
+extern "C" int ufnd_meanpool_l2_packed(const float* hidden, const int32_t* cu_seqlens, const int32_t* pos_ids, float* out, int B, int H,
+                                       void* stream_) {
+  UFND_REQUIRE(hidden && cu_seqlens && pos_ids && out && B >= 1, "meanpool_packed: null argument");
+  UFND_REQUIRE(H >= 256 && H % 256 == 0 && ufnd_aligned(hidden, 16) && ufnd_aligned(out, 16), "meanpool_packed: H=%d (multiple of 256)", H);
+  hipLaunchKernelGGL(meanpool_packed_kernel, dim3(H / 256, B), dim3(256), 0, (hipStream_t)stream_, hidden, cu_seqlens, pos_ids, out, H);
   UFND_CHECK_LAUNCH();
   hipLaunchKernelGGL(l2norm_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream_, out, H);
   UFND_CHECK_LAUNCH();

@@ -237,29 +237,29 @@ class BertTextEncoder(_EncoderBase):
                                         w["embeddings.LayerNorm.weight"].data_ptr(), w["embeddings.LayerNorm.bias"].data_ptr(),
                                         b["xb"].data_ptr(), b["xf"].data_ptr(), B, Lq, H, self.vocab, self.eps,
                                         L.stream_ptr(dev)), "ufnd_bert_embed")
-        if "st1" in b:
-            return self._layers_folded(p, b, mask, B, Lq)
-        for ly in p["layers"]:
-            self._gemm(b["xb"], ly["wqkv"], ly["bqkv"], out_bf16=b["qkv"])
-            self._attn(b["qkv"], mask, b["ctx"], B, Lq, self.heads)
-            self._gemm(b["ctx"], ly["wo"], ly["bo"], out_f32=b["y"], residual=b["xf"])
-            self._ln(b["y"], H, ly["g1"], ly["b1"], b["x1b"], b["x1f"], M, H, self.eps)
-            self._gemm(b["x1b"], ly["w1"], ly["bi"], out_bf16=b["h"], act=ACT_GELU)
-            if self.ffn2_split > 1:
-                # output.dense (K = 3072): split-K partial slabs, reduced + bias + residual inside the LayerNorm
-                self._gemm(b["h"], ly["w2"], None, slabs=b["slabs"])
-                L.check(L.lib().ufnd_layernorm_sum(b["slabs"].data_ptr(), self.ffn2_split, ly["b2"].data_ptr(), b["x1f"].data_ptr(), H,
-                                               ly["g2"].data_ptr(), ly["b2n"].data_ptr(), b["xb"].data_ptr(), b["xf"].data_ptr(), None,
-                                               M, H, self.eps, L.stream_ptr(dev)), "ufnd_layernorm_sum")
-            else:
-                self._gemm(b["h"], ly["w2"], ly["b2"], out_f32=b["y"], residual=b["x1f"])
-                self._ln(b["y"], H, ly["g2"], ly["b2n"], b["xb"], b["xf"], M, H, self.eps)
+        self._layers(p, b, M, lambda qkv, ctx: self._attn(qkv, mask, ctx, B, Lq, self.heads))
         return b["xf"].view(B, Lq, H)
 
-    def _layers_folded(self, p, b, mask, B, Lq):
-        """The 12 layers without a LayerNorm kernel between Linears (module docstring).  y1 / y2 are the
+    def _layers(self, p, b, M, attn) -> None:
+        """The encoder layers over the first M rows of the work buffers; attn(qkv, ctx) runs the attention (padded
+        batch or packed sequences).  Leaves last_hidden_state in b["xf"] (and its bf16 rounding in b["xb"])."""
+        H = self.hidden
+        v = {k: (x[:M] if torch.is_tensor(x) and x.dim() >= 2 and x.shape[0] >= M and k not in ("slabs", "feat") else x) for k, x in b.items()}
+        if "st1" in b:
+            return self._layers_folded(p, v, M, attn)
+        for ly in p["layers"]:
+            self._gemm(v["xb"], ly["wqkv"], ly["bqkv"], out_bf16=v["qkv"])
+            attn(v["qkv"], v["ctx"])
+            self._gemm(v["ctx"], ly["wo"], ly["bo"], out_f32=v["y"], residual=v["xf"])
+            self._ln(v["y"], H, ly["g1"], ly["b1"], v["x1b"], v["x1f"], M, H, self.eps)
+            self._gemm(v["x1b"], ly["w1"], ly["bi"], out_bf16=v["h"], act=ACT_GELU)
+            self._gemm(v["h"], ly["w2"], ly["b2"], out_f32=v["y"], residual=v["x1f"])
+            self._ln(v["y"], H, ly["g2"], ly["b2n"], v["xb"], v["xf"], M, H, self.eps)
+
+    def _layers_folded(self, p, b, M, attn) -> None:
+        """The layers without a LayerNorm kernel between Linears (module docstring).  y1 / y2 are the
         PRE-LayerNorm sums of the attention and the feed-forward halves (fp32 + bf16 + row statistics)."""
-        M, H, eps = B * Lq, self.hidden, self.eps
+        H, eps = self.hidden, self.eps
         y1, y2 = b["y"], b["y2"]
         prev = None
         for ly in p["layers"]:
@@ -267,7 +267,7 @@ class BertTextEncoder(_EncoderBase):
                 self._gemm(b["xb"], ly["wqkv"], ly["bqkv"], out_bf16=b["qkv"])
             else:
                 self._gemm_ln(b["y2b"], ly["wqkvf"], ly["bqkvf"], out_bf16=b["qkv"], a_stats=b["st2"], colsum=ly["csqkv"], eps=eps)
-            self._attn(b["qkv"], mask, b["ctx"], B, Lq, self.heads)
+            attn(b["qkv"], b["ctx"])
             if prev is None:
                 self._gemm_ln(b["ctx"], ly["wo"], ly["bo"], out_f32=y1, out_bf16=b["y1b"], residual=b["xf"], out_stats=b["st1"], eps=eps)
             else:
@@ -278,11 +278,15 @@ class BertTextEncoder(_EncoderBase):
                           r_gamma=ly["g1"], r_beta=ly["b1"], out_stats=b["st2"], eps=eps)
             prev = ly
         self._ln(y2, H, prev["g2"], prev["b2n"], b["xb"], b["xf"], M, H, eps)      # last_hidden_state is materialised once
-        return b["xf"].view(B, Lq, H)
 
     @torch.no_grad()
-    def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
-        """Batched BERTContextEncoder.encode: (B,L) ids/mask -> (B,768) L2-normalised features."""
+    def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, unpad: bool = False) -> torch.Tensor:
+        """Batched BERTContextEncoder.encode: (B,L) ids/mask -> (B,768) L2-normalised features.
+        unpad=True runs the encoder over the kept tokens only (packed rows, per-sequence attention): the padded
+        positions never reach the pooling (text_blocks.py:82-86), so no returned value changes -- bit-identical for
+        prefix masks -- while the work drops with the padding fraction.  Shapes vary per batch: not for hipGraph capture."""
+        if unpad:
+            return self._forward_packed(input_ids, attention_mask)
         hid = self.last_hidden_state(input_ids, attention_mask)
         B, Lq, H = hid.shape
         feat = self._workbufs(B, Lq)["feat"]
@@ -290,11 +294,45 @@ class BertTextEncoder(_EncoderBase):
                                                 L.stream_ptr(self.device)), "ufnd_masked_meanpool_l2")
         return feat
 
+    def _forward_packed(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
+        self._require_hip()
+        dev = self.device
+        B, Lq = input_ids.shape
+        if Lq > self.max_position:
+            raise RuntimeError(f"sequence length {Lq} exceeds max_position_embeddings {self.max_position}")
+        ids = input_ids.to(dev, torch.int64).reshape(-1)
+        mask = attention_mask.to(dev, torch.int32).contiguous()
+        keep = torch.nonzero(mask.reshape(-1), as_tuple=False).flatten()          # (host sync: the packed row count)
+        T = int(keep.numel())
+        p, b, w = self._pack(), self._workbufs(B, Lq), self._w
+        H, s = self.hidden, L.stream_ptr(dev)
+        feat = b["feat"]
+        if T == 0:
+            return feat.zero_()
+        ids_p = ids[keep].contiguous()
+        pos = (keep % Lq).to(torch.int32).contiguous()
+        cu = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+        cu[1:] = torch.cumsum(mask.sum(1, dtype=torch.int32), 0)
+        L.check(L.lib().ufnd_bert_embed_packed(ids_p.data_ptr(), pos.data_ptr(), w["embeddings.word_embeddings.weight"].data_ptr(),
+                                               w["embeddings.position_embeddings.weight"].data_ptr(),
+                                               w["embeddings.token_type_embeddings.weight"].data_ptr(),
+                                               w["embeddings.LayerNorm.weight"].data_ptr(), w["embeddings.LayerNorm.bias"].data_ptr(),
+                                               b["xb"].data_ptr(), b["xf"].data_ptr(), T, self.max_position, H, self.vocab, self.eps, s),
+                "ufnd_bert_embed_packed")
+
+        def attn(qkv, ctx):
+            L.check(L.lib().ufnd_attention_bf16_varlen(qkv.data_ptr(), cu.data_ptr(), ctx.data_ptr(), B, Lq, self.heads, s),
+                    "ufnd_attention_bf16_varlen")
+        self._layers(p, b, T, attn)
+        L.check(L.lib().ufnd_meanpool_l2_packed(b["xf"].data_ptr(), cu.data_ptr(), pos.data_ptr(), feat.data_ptr(), B, H, s),
+                "ufnd_meanpool_l2_packed")
+        return feat
+
     encode_batch = forward
 
     @torch.no_grad()
     def encode_fields(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, part_valid: torch.Tensor,
-                      chunk: int = 1024) -> torch.Tensor:
+                      chunk: int = 1024, unpad: bool = True) -> torch.Tensor:
         """Batched BERTContextEncoder.encode_fields (text_blocks.py:108-128).
         input_ids / attention_mask (N, M, L): the tokenised parts of N records in the reference's
         order [title, ocr, up to 10 comments] (M <= 12); part_valid (N, M): 1 where the part exists
@@ -311,7 +349,7 @@ class BertTextEncoder(_EncoderBase):
         parts = torch.zeros(N * Mx, self.hidden, dtype=torch.float32, device=dev)
         for s0 in range(0, rows.numel(), chunk):
             r = rows[s0:s0 + chunk]
-            parts[r] = self.forward(ids[r], mask[r])
+            parts[r] = self.forward(ids[r], mask[r], unpad=unpad)      # (texts are short against max_length: skip the padding)
         out = torch.empty(N, self.hidden, dtype=torch.float32, device=dev)
         L.check(L.lib().ufnd_field_mean_l2(parts.data_ptr(), valid.data_ptr(), out.data_ptr(), N, Mx, self.hidden,
                                            L.stream_ptr(dev)), "ufnd_field_mean_l2")
