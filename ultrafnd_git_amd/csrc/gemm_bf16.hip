@@ -586,14 +586,18 @@ static int launch_cfg(int cfg, int abl, GemmArgs& a, hipStream_t stream) {
 #define X(id, BM_, BN_, WM_, WN_, SA_, SB_, MI_, LN_)                                                              \
   case id:                                                                                                          \
     if constexpr (SA_ * BM_ * 128 + SB_ * BN_ * 128 <= 160 * 1024) {                                                \
-      if (abl == 4) {                                                                                               \
-        if constexpr (LN_ != 0) hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, SA_, SB_, MI_, 0, 0, 1>), grid, block, 0, stream, a); \
-      } else if (abl == 5) {                                                                                        \
-        if constexpr (LN_ != 0) hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, SA_, SB_, MI_, 0, 1, 1>), grid, block, 0, stream, a); \
-      } else if (abl == 0) hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, SA_, SB_, MI_, 0, 0>), grid, block, 0, stream, a);      \
-      else if (abl == 1) hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, SA_, SB_, MI_, 1, 0>), grid, block, 0, stream, a); \
-      else if (abl == 2) hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, SA_, SB_, MI_, 2, 0>), grid, block, 0, stream, a); \
-      else hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, SA_, SB_, MI_, 0, 1>), grid, block, 0, stream, a);   \
+      if (abl == 0) {                                                                                               \
+        hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, SA_, SB_, MI_, 0, 0>), grid, block, 0, stream, a); \
+      } else if constexpr (LN_ != 0) { /* diagnostics and LayerNorm-aware builds exist for the tiles in use only */ \
+        if (abl == 4) hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, SA_, SB_, MI_, 0, 0, 1>), grid, block, 0, stream, a);      \
+        else if (abl == 5) hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, SA_, SB_, MI_, 0, 1, 1>), grid, block, 0, stream, a); \
+        else if (abl == 1) hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, SA_, SB_, MI_, 1, 0>), grid, block, 0, stream, a);    \
+        else if (abl == 2) hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, SA_, SB_, MI_, 2, 0>), grid, block, 0, stream, a);    \
+        else hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, SA_, SB_, MI_, 0, 1>), grid, block, 0, stream, a);                  \
+      } else {                                                                                                      \
+        ufnd_set_error("gemm_bf16: tile %d has no diagnostics / LayerNorm-aware build", id);                        \
+        return UFND_ERR_INVALID;                                                                                    \
+      }                                                                                                             \
     }                                                                                                               \
     break;
   switch (cfg) {
