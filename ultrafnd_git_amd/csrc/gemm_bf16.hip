@@ -21,6 +21,10 @@
 // all tile shapes emit the same floating-point operation sequence (rows are batch-invariant, bit for bit).
 #pragma clang fp contract(off)
 
+#ifndef UFND_GEMM_ILV
+#define UFND_GEMM_ILV 1      // 1: fragment reads interleaved with the leading MFMAs of a k-half (0: issued as one burst)
+#endif
+
 namespace {
 
 constexpr int BK = 64;
@@ -297,14 +301,25 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
   // half a step of queued matrix work on either side.  One MFMA leads each half so that the wait the
   // compiler places in front of it covers only reads issued half a step earlier.
   constexpr int NMF = KQ * MT * NT, NRD = KQ * (MT + NT);
+  constexpr bool ILV = UFND_GEMM_ILV != 0;
   auto body = [&](int t, auto ia_, auto ib_, auto next_) {
     constexpr bool IA = decltype(ia_)::value != 0, IB = decltype(ib_)::value != 0, NEXT = decltype(next_)::value != 0;
     if constexpr (ABL != 1) {
       read_half(t, IntC<1>{}, af1, bf1);
       mma_half(af0, bf0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1, 0);
+      if constexpr (ILV) {            // one fragment read behind each of the first MFMAs: the matrix pipe is never left
+#pragma unroll                        // waiting behind a burst of NRD LDS instructions of both waves of the SIMD
+        for (int q = 0; q < (NRD < NMF ? NRD : NMF - 1); ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, NRD - (NRD < NMF ? NRD : NMF - 1), 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF - (NRD < NMF ? NRD : NMF - 1), 0);
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1, 0);
+      }
     }
     if constexpr (NEXT) {
       __builtin_amdgcn_sched_barrier(0);
@@ -325,14 +340,29 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
       mma_half(af1, bf1);
       constexpr int PW = (ABL == 2 || !NEXT) ? 0 : (IA ? PWA : 0) + (IB ? PWB : 0);
       constexpr int GRP = (NMF - 1) / (PW + 1) > 0 ? (NMF - 1) / (PW + 1) : 1;
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if constexpr (NEXT) __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+      if constexpr (ILV && NEXT && NRD + PW < NMF) {
 #pragma unroll
-      for (int q = 0; q < PW; ++q) {
-        __builtin_amdgcn_sched_group_barrier(0x008, GRP, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        for (int q = 0; q < NRD; ++q) {           // {MFMA, fragment read} x NRD
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        constexpr int REST = NMF - NRD, G2 = REST / (PW + 1) > 0 ? REST / (PW + 1) : 1;
+#pragma unroll
+        for (int q = 0; q < PW; ++q) {            // {G2 MFMA, DMA piece} x PW
+          __builtin_amdgcn_sched_group_barrier(0x008, G2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, REST - G2 * PW > 0 ? REST - G2 * PW : 0, 0);
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (NEXT) __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+#pragma unroll
+        for (int q = 0; q < PW; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, GRP, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1 - GRP * PW > 0 ? NMF - 1 - GRP * PW : 0, 0);
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1 - GRP * PW > 0 ? NMF - 1 - GRP * PW : 0, 0);
     }
   };
 
