@@ -141,6 +141,12 @@ def main():
         empty = empty_pair_ms()
         cold = "--cold" in sys.argv
         junk = torch.empty(96 << 20, dtype=torch.uint8, device=DEV) if cold else None
+        # --rotate=R: R copies of the operands, a different one per launch (R x (A + W) beyond the 256 MiB Infinity Cache
+        # means every launch streams its operands from HBM, like a layer's weights inside the encoder pass)
+        rot = max([int(a.split("=")[1]) for a in sys.argv if a.startswith("--rotate=")] + [1])
+        As = [A] + [A.clone() for _ in range(rot - 1)] if "--rotate-w-only" not in sys.argv else [A] * rot
+        Ws = [W] + [W.clone() for _ in range(rot - 1)] if "--rotate-a-only" not in sys.argv else [W] * rot
+        ctr = 0
         for _ in range(rounds):
             for c in variants:
                 evs = []
@@ -149,7 +155,8 @@ def main():
                     if cold:
                         junk.add_(1)                   # 192 MB of traffic: L2 and part of the MALL turn over
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(); run(c, A, W, bias, ob, M, N, K, name); e1.record()
+                    ctr += 1
+                    e0.record(); run(c, As[ctr % rot], Ws[ctr % rot], bias, ob, M, N, K, name); e1.record()
                     evs.append((e0, e1))
                 torch.cuda.synchronize()
                 times[c] += [a.elapsed_time(b) - empty for a, b in evs]

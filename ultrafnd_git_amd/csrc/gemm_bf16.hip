@@ -591,7 +591,7 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* src, __bf16
   X(19, 64, 64, 1, 2, 4, 4, 16, 0)    /*  64 KiB (2 blocks/CU) */                                             \
   X(20, 128, 64, 4, 2, 4, 4, 16, 1)   /*  96 KiB (8 waves, wave tile 32x32) */                                \
   X(21, 256, 192, 2, 4, 2, 2, 16, 0)  /* 112 KiB (wave tile 128x48) */                                        \
-  X(22, 256, 192, 4, 2, 3, 2, 16, 0)  /* 144 KiB: A two K-steps ahead, W one */                               \
+  X(22, 256, 192, 4, 2, 3, 2, 16, 1)  /* 144 KiB: A two K-steps ahead, W one */                               \
   X(23, 256, 256, 4, 2, 3, 2, 16, 0)  /* 160 KiB */                                                           \
   X(24, 128, 192, 4, 2, 4, 4, 16, 0)  /* 160 KiB */                                                           \
   X(25, 128, 256, 4, 2, 3, 3, 16, 0)  /* 144 KiB (8 waves, wave tile 32x128) */                               \
@@ -649,7 +649,10 @@ static int auto_cfg(int M, int N, int K) {
   // (256x144 gives BERT QKV 256 tiles instead of 192 and is 8 % faster alone -- 17.2 vs 18.8 us -- but the step got
   //  4 % SLOWER with it: the 64 CUs the 192-tile launch leaves free are where the other encoder's and the head's
   //  kernels run meanwhile.  Tile 28 stays in the table for the sweep; it is not selected.)
-  if (N % 192 == 0 && tiles(8) >= 160) return 8;      // 256x192: BERT QKV (192 tiles) / FFN1 (256)
+  // 256x192: BERT QKV (192 tiles) / FFN1 (256).  The A ring is 3 slots deep (tile 22, not 8): inside the encoder the
+  // activation operand was just written by the previous kernel and comes from the Infinity Cache / HBM, not from L2
+  // (gemm_sweep --rotate=40: 21.6 -> 19.4 us on QKV, 26.8 -> 24.7 on FFN1; cold WEIGHTS cost under 1 us either way)
+  if (N % 192 == 0 && tiles(22) >= 160) return 22;
   if (N >= 2048) {                                     // wide N, fewer rows (ViT QKV / FFN1): 32-row wave tiles
     if (N % 192 == 0 && N >= 3072) return 17;          //   128x192
     if (N % 128 == 0) return 16;                       //   128x128
