@@ -12,7 +12,8 @@ from typing import Optional
 import torch
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "libultrafnd_hip.so"
+import os as _os
+LIB_PATH = Path(_os.environ.get("UFND_LIB", _PKG / "libultrafnd_hip.so"))      # (UFND_LIB: A/B of two builds in one run)
 
 
 class UltrafndHipError(RuntimeError):

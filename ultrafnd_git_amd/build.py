@@ -40,6 +40,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-Wno-pass-failed", "-o", str(LIB)] + [str(s) for s in sources()]
+    if os.environ.get("UFND_BUILD_DEFS"):          # experiments: extra -D switches (e.g. UFND_GEMM_WT=1)
+        cmd[1:1] = ["-D" + d for d in os.environ["UFND_BUILD_DEFS"].split(",")]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))
