@@ -199,7 +199,7 @@ def main():
                                        "tflops": round(2.0 * eval(k.replace("x", "*")) / (v[1] / v[0] * 1e-3) / 1e12, 1)}
                                    for k, v in tr.last_gemm_by_shape.items()}}
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # (the CPU leg is timed at N = 1 only)
         cpu = cpu_baseline(B)
     if rank == 0:
         value = world * B * args.steps / dt
