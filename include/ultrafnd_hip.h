@@ -260,18 +260,6 @@ int ufnd_gemm_bf16_stamps(const void* A, const void* W, void* out_bf16, int M, i
                           unsigned long long* stamps, const ufnd_gemm_ln* ln, const float* bias, const float* residual,
                           float* out_f32, void* stream);
 
-/* Split-K form for narrow-N / long-K Linears (BERT output.dense, K = 3072): K is cut into `ksplit`
- * slices, block (tile, s) writes the raw fp32 partial product of slice s to slabs[s] ((M,N), row
- * stride N); bias / residual / LayerNorm are applied by ufnd_layernorm_sum, which has to read the rows
- * anyway.  Halves the L2->LDS operand traffic per CU (the bound of this kernel) at equal block count. */
-int ufnd_gemm_bf16_splitk(const void* A, const void* W, float* slabs, int M, int N, int K, int lda, int ldw, int ksplit,
-                          int tile_cfg, void* stream);
-
-/* x = sum_s slabs[s] + bias + residual; sum_out (optional) receives x; then LayerNorm as below. */
-int ufnd_layernorm_sum(const float* slabs, int S, const float* bias, const float* residual, int ldr, const float* gamma,
-                       const float* beta, void* out_bf16, float* out_f32, float* sum_out, int M, int H, float eps,
-                       void* stream);
-
 /* y = LayerNorm(x) * gamma + beta over the last dim (H % 256 == 0, H <= 1024).
  *   x fp32 rows with stride ldx; outputs (M,H) contiguous: bf16 (next GEMM's operand) and/or
  *   fp32 (the residual stream). */

@@ -102,8 +102,6 @@ def _declare_encoders(lib: C.CDLL) -> None:
         "ufnd_gemm_bf16_ex": [P] * 6 + [I] * 10 + [P],
         "ufnd_gemm_bf16_stamps": [P, P, P, I, I, I, I, P, C.POINTER(GemmLn), P, P, P, P],
         "ufnd_layernorm": [P, I, P, P, P, P, I, I, F, P],
-        "ufnd_gemm_bf16_splitk": [P, P, P, I, I, I, I, I, I, I, P],
-        "ufnd_layernorm_sum": [P, I, P, P, I, P, P, P, P, P, I, I, F, P],
         "ufnd_attention_bf16": [P, P, P, I, I, I, P],
         "ufnd_bert_embed": [P] * 8 + [I, I, I, I, F, P],
         "ufnd_masked_meanpool_l2": [P, P, P, I, I, I, P],

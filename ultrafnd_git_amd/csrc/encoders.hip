@@ -72,31 +72,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, int ldx,
   store_row<NI>(v, ob, of, row, H, lane);
 }
 
-// x = sum_s slab_s + bias + residual (the split-K partials of the preceding GEMM are reduced here,
-// in the kernel that has to read the row anyway); optional copy of x; then LayerNorm.
-template <int NI>
-__global__ __launch_bounds__(256) void layernorm_sum_kernel(const float* slabs, int S, size_t slab_stride, const float* bias,
-                                                            const float* residual, int ldr, const float* gamma,
-                                                            const float* beta, __bf16* ob, float* of, float* sum_out, int M,
-                                                            int H, float eps) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
-  f32x4 v[NI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int col = 4 * lane + 256 * i;
-    f32x4 x = ld4(slabs + (size_t)row * H + col);
-    for (int sidx = 1; sidx < S; ++sidx) x += ld4(slabs + sidx * slab_stride + (size_t)row * H + col);
-    if (bias) x += ld4(bias + col);
-    if (residual) x += ld4(residual + (size_t)row * ldr + col);
-    v[i] = x;
-    if (sum_out) *reinterpret_cast<f32x4*>(sum_out + (size_t)row * H + col) = x;
-  }
-  ln_row<NI>(v, H, eps, gamma, beta, lane);
-  store_row<NI>(v, ob, of, row, H, lane);
-}
-
 template <int NI>
 __global__ __launch_bounds__(256) void bert_embed_kernel(const int64_t* ids, const float* word, const float* pos,
                                                          const float* type0, const float* gamma, const float* beta,
@@ -303,19 +278,6 @@ extern "C" int ufnd_layernorm(const float* x, int ldx, const float* gamma, const
                "layernorm: alignment");
   NI_LAUNCH(H, layernorm_kernel, dim3(ufnd_cdiv(M, 4)), (hipStream_t)stream_, x, ldx, gamma, beta, (__bf16*)out_bf16,
             out_f32, M, H, eps);
-  UFND_CHECK_LAUNCH();
-  return UFND_OK;
-}
-
-extern "C" int ufnd_layernorm_sum(const float* slabs, int S, const float* bias, const float* residual, int ldr, const float* gamma,
-                                  const float* beta, void* out_bf16, float* out_f32, float* sum_out, int M, int H, float eps,
-                                  void* stream_) {
-  UFND_REQUIRE(slabs && gamma && beta && (out_bf16 || out_f32) && M >= 1 && S >= 1 && S <= 8, "layernorm_sum: null argument");
-  UFND_REQUIRE(h_ok(H), "layernorm_sum: H=%d (supported 256/512/768/1024)", H);
-  UFND_REQUIRE(ufnd_aligned(slabs, 16) && (!residual || (ldr % 4 == 0 && ufnd_aligned(residual, 16))) && (!bias || ufnd_aligned(bias, 16)),
-               "layernorm_sum: alignment");
-  NI_LAUNCH(H, layernorm_sum_kernel, dim3(ufnd_cdiv(M, 4)), (hipStream_t)stream_, slabs, S, (size_t)M * H, bias, residual, ldr, gamma,
-            beta, (__bf16*)out_bf16, out_f32, sum_out, M, H, eps);
   UFND_CHECK_LAUNCH();
   return UFND_OK;
 }

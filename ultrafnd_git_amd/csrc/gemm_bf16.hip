@@ -38,7 +38,7 @@ struct GemmArgs {
   float* out_f32;
   int M, N, K, lda, ldw, ldr, ldo, ldf, act;
   int m_tiles, n_tiles;
-  int ksplit;            // > 1: block (tile, s) multiplies K-slice s and writes raw fp32 partials to slab s
+  int ksplit;            // K slices (1 in every entry point; the kernel keeps the indexing)
   unsigned long long* stamps;   // DBG builds only
   // LayerNorm extras (LNX kernels only; every pointer optional)
   const float* a_stats;  // (M, a_parts, 2) partial {sum, sumsq} of the fp32 rows A was rounded from: LayerNorm of A folded in
@@ -680,23 +680,6 @@ extern "C" int ufnd_gemm_bf16_ex(const void* A, const void* W, const float* bias
   UFND_REQUIRE(cfg < kNumTiles, "gemm_bf16: unknown tile config %d", cfg);
   UFND_REQUIRE(N % kTiles[cfg].bn == 0, "gemm_bf16: tile config %d needs N %% %d == 0", cfg, kTiles[cfg].bn);
   int rc = launch_cfg(cfg, abl, a, (hipStream_t)stream_);
-  if (rc != UFND_OK) return rc;
-  UFND_CHECK_LAUNCH();
-  return UFND_OK;
-}
-
-extern "C" int ufnd_gemm_bf16_splitk(const void* A, const void* W, float* slabs, int M, int N, int K, int lda, int ldw, int ksplit,
-                                     int tile_cfg, void* stream_) {
-  UFND_REQUIRE(A && W && slabs, "gemm_bf16_splitk: null operand");
-  UFND_REQUIRE(ksplit >= 1 && ksplit <= 8 && K % (64 * ksplit) == 0, "gemm_bf16_splitk: K=%d not divisible into %d slices of 64-steps", K, ksplit);
-  UFND_REQUIRE(M >= 1 && N >= 64 && N % 64 == 0, "gemm_bf16_splitk: M=%d N=%d", M, N);
-  UFND_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K && ufnd_aligned(A, 16) && ufnd_aligned(W, 16) && ufnd_aligned(slabs, 16),
-               "gemm_bf16_splitk: alignment");
-  GemmArgs a{(const __bf16*)A, (const __bf16*)W, nullptr, nullptr, nullptr, slabs, M, N, K, lda, ldw, 0, 0, N, 0, 0, 0, ksplit, nullptr};
-  int cfg = tile_cfg < 0 ? 17 : tile_cfg;     // 128x192, 8 waves
-  if (N % kTiles[cfg < kNumTiles ? cfg : 0].bn != 0) cfg = 1;
-  UFND_REQUIRE(cfg < kNumTiles && N % kTiles[cfg].bn == 0, "gemm_bf16_splitk: tile config %d does not divide N=%d", cfg, N);
-  int rc = launch_cfg(cfg, 0, a, (hipStream_t)stream_);
   if (rc != UFND_OK) return rc;
   UFND_CHECK_LAUNCH();
   return UFND_OK;

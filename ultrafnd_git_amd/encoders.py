@@ -87,13 +87,9 @@ class _EncoderBase(nn.Module):
             raise L.UltrafndHipError(f"{type(self).__name__} runs on a HIP device only: call .to('cuda') (no CPU fallback)")
 
     # ---- thin wrappers over the C ABI
-    def _gemm(self, A, W, bias, out_bf16=None, out_f32=None, residual=None, act=ACT_NONE, M=None, slabs=None):
+    def _gemm(self, A, W, bias, out_bf16=None, out_f32=None, residual=None, act=ACT_NONE, M=None):
         M = A.shape[0] if M is None else M
         N, K = W.shape
-        if slabs is not None:       # split-K: raw partials per K-slice, reduced by ufnd_layernorm_sum
-            L.check(L.lib().ufnd_gemm_bf16_splitk(A.data_ptr(), W.data_ptr(), slabs.data_ptr(), M, N, K, A.stride(0), W.stride(0),
-                                                  slabs.shape[0], -1, L.stream_ptr(A.device)), "ufnd_gemm_bf16_splitk")
-            return
         L.check(L.lib().ufnd_gemm_bf16(A.data_ptr(), W.data_ptr(), L.ptr(bias), L.ptr(residual), L.ptr(out_bf16),
                                        L.ptr(out_f32), M, N, K, A.stride(0), W.stride(0),
                                        residual.stride(0) if residual is not None else 0,
@@ -150,7 +146,6 @@ class BertTextEncoder(_EncoderBase):
         self.layers, self.hidden, self.heads, self.inter, self.vocab, self.eps = layers, hidden, heads, intermediate, vocab_size, eps
         self.max_position = max_position
         # output.dense as a 2-way split-K GEMM when the token count gives a full wave of 128x192 tiles
-        self.ffn2_split = 1      # (a 2-way split-K + slab-summing LayerNorm lost to the direct 128x128 GEMM)
         w = self._w
         g = torch.Generator().manual_seed(0)
 
@@ -206,7 +201,6 @@ class BertTextEncoder(_EncoderBase):
             dev, M, H = self.device, B * Lq, self.hidden
             bf, f32 = dict(dtype=torch.bfloat16, device=dev), dict(dtype=torch.float32, device=dev)
             self._bufs[key] = {"xb": torch.empty(M, H, **bf), "xf": torch.empty(M, H, **f32), "y": torch.empty(M, H, **f32),
-                               "slabs": torch.empty(self.ffn2_split, M, H, **f32),
                                "x1b": torch.empty(M, H, **bf), "x1f": torch.empty(M, H, **f32),
                                "qkv": torch.empty(M, 3 * H, **bf), "ctx": torch.empty(M, H, **bf),
                                "h": torch.empty(M, self.inter, **bf), "feat": torch.empty(B, H, **f32)}
@@ -244,7 +238,7 @@ class BertTextEncoder(_EncoderBase):
         """The encoder layers over the first M rows of the work buffers; attn(qkv, ctx) runs the attention (padded
         batch or packed sequences).  Leaves last_hidden_state in b["xf"] (and its bf16 rounding in b["xb"])."""
         H = self.hidden
-        v = {k: (x[:M] if torch.is_tensor(x) and x.dim() >= 2 and x.shape[0] >= M and k not in ("slabs", "feat") else x) for k, x in b.items()}
+        v = {k: (x[:M] if torch.is_tensor(x) and x.dim() >= 2 and x.shape[0] >= M and k != "feat" else x) for k, x in b.items()}
         if "st1" in b:
             return self._layers_folded(p, v, M, attn)
         for ly in p["layers"]:
