@@ -333,6 +333,29 @@ int ufnd_temporal_align(const float* text, const float* visual, const float* w0,
                         int out_dim, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * TemporalSyncNet.forward, the sequence path   src/core_blocks/temporal_blocks.py:141-157, _TinyTCN :16-43
+ *   text_seq (B,T,text_dim), vis_seq (B,T,vis_dim) fp32, channel-last; in_ch = text_dim + vis_dim.
+ *   Per block i: Conv1d(ch -> hid, kernel, padding 'same', dilation 2^i) -> BatchNorm1d -> GELU -> dropout, added to
+ *   its input when the widths match; then out (B,out_dim) = head([mean_t h, max_t h]).
+ *   layer.w is the Conv1d weight (hid, ch, kernel) re-packed tap-major: w[h][j*ch + c] = weight[h][c][j], row stride
+ *   ufnd_tcn_weight_ld(ch, kernel) (ch*kernel rounded up to a multiple of 4, pad zero).  head_w (out_dim, 2*hid).
+ *   train != 0: batch statistics (and the running_mean / running_var update, `momentum`), dropout keyed by `state`;
+ *   train == 0: running statistics, no dropout.  Forward only (nothing in the reference trains this module).
+ *   workspace: ufnd_tcn_workspace_floats(B, T, in_ch, hid, kernel) floats.
+ * ---------------------------------------------------------------------------------- */
+typedef struct ufnd_tcn_layer {
+  const float *w, *b;                 /* packed conv weight, bias (hid) */
+  const float *gamma, *beta;          /* BatchNorm1d weight, bias (hid) */
+  float *running_mean, *running_var;  /* (hid); written when train != 0 */
+} ufnd_tcn_layer;
+int ufnd_tcn_weight_ld(int in_ch, int kernel);
+size_t ufnd_tcn_workspace_floats(int B, int T, int in_ch, int hid, int kernel);
+int ufnd_tcn_forward(const float* text_seq, int text_dim, const float* vis_seq, int vis_dim, int B, int T,
+                     const ufnd_tcn_layer* layers, int n_layers, int kernel, int hid, const float* head_w,
+                     const float* head_b, int out_dim, int train, float dropout_p, float momentum, float eps,
+                     const ufnd_step_state* state, float* workspace, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Graph side of the trainer's construction: src/training/forensic_trainer.py
  *   build_adj_from_ocr :114-132, SimpleGCN :25-53, ForensicTrainer._pretrain_gnn :214-224.
  * Init-time work in the reference (an O(N^2) Python loop and dense (N,N) products on the CPU).

@@ -16,6 +16,8 @@ What it does
            tensors, per-tensor digests for grads/params) in tier_a_B*.npz.
   metrics  runs the reference's forensic_metrics on known inputs -> metrics_kat.json.
   temporal runs the reference's TemporalSyncNet.align on seeded weights -> temporal.npz.
+  temporal_seq runs the reference's TemporalSyncNet(use_tcn=True).forward (eval, and train with dropout p=0) on seeded
+           weights for four geometries -> temporal_seq.npz; also delay_score / estimate_av_lag known answers.
   gcn      runs the reference's build_adj_from_ocr / SimpleGCN (forward, two Adam pre-training steps with
            dropout p=0) on synthetic phrase sets -> gcn.npz.
   tier_b   builds the locally installed third-party BertModel / CLIPVisionModelWithProjection
@@ -347,6 +349,78 @@ def temporal():
     print("temporal: oracle-vs-reference max-abs-err", (ref - ora).abs().max().item())
 
 
+SEQ_CASES = [  # name, in_dim, out_dim, hid, layers, k, B, T, Dt
+    ("a", 96, 64, 64, 2, 3, 3, 10, 64),       # widths differ at block 0 (no residual there), residual at block 1
+    ("b", 64, 32, 64, 3, 3, 2, 9, 32),        # in_dim == hid: residual at every block; dilations 1, 2, 4 > T/2
+    ("c", 48, 32, 32, 2, 4, 2, 7, 20),        # even kernel: 'same' pads asymmetrically
+    ("d", 40, 32, 32, 2, 5, 4, 1, 24),        # T = 1 clips; kernel 5
+]
+
+
+def temporal_seq():
+    """TemporalSyncNet.forward, the sequence path (src/core_blocks/temporal_blocks.py:16-43,141-157), and the two
+    host-side delay estimators (:162-226)."""
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, str(REF))
+    from src.core_blocks.temporal_blocks import TemporalSyncNet
+    from oracle import temporal_ref as T
+    store = {}
+    worst = 0.0
+    for n, (name, in_dim, out_dim, hid, layers, k, B, Tn, Dt) in enumerate(SEQ_CASES):
+        w = T.seq_seeded_weights(70 + n, in_dim, out_dim, hid, layers, k)
+        net = TemporalSyncNet(in_dim=in_dim, out_dim=out_dim, use_tcn=True, tcn_hid=hid, tcn_layers=layers, tcn_kernel=k, dropout=0.0).to("cpu")
+        assert list(net.state_dict().keys()) == list(w.keys()), (list(net.state_dict().keys()), list(w.keys()))
+        net.load_state_dict(w)
+        g = torch.Generator().manual_seed(80 + n)
+        ts, vs = torch.randn(B, Tn, Dt, generator=g), torch.randn(B, Tn, in_dim - Dt, generator=g)
+        net.eval()
+        with torch.no_grad():
+            out_eval = net(ts, vs)
+        net.train()
+        with torch.no_grad():
+            out_train = net(ts, vs)
+        sd = net.state_dict()
+        o_eval, _ = T.sequence_forward(w, ts, vs, layers, k, train=False)
+        o_train, stats = T.sequence_forward(w, ts, vs, layers, k, train=True)
+        errs = [(out_eval - o_eval).abs().max().item(), (out_train - o_train).abs().max().item()]
+        errs += [(sd[kk] - vv).abs().max().item() for kk, vv in stats.items()]
+        assert max(errs) <= 2e-5, (name, errs)
+        worst = max(worst, max(errs))
+        store.update({f"{name}/text_seq": ts.numpy(), f"{name}/vis_seq": vs.numpy(), f"{name}/out_eval": out_eval.numpy(),
+                      f"{name}/out_train": out_train.numpy(), f"{name}/weight_seed": np.int64(70 + n),
+                      f"{name}/checksum": np.float64(sum(x.double().sum() for x in w.values()))})
+        for i in range(layers):
+            for s_ in ("running_mean", "running_var"):
+                store[f"{name}/after/tcn.norms.{i}.{s_}"] = sd[f"tcn.norms.{i}.{s_}"].numpy()
+    # delay estimators: known answers from the reference's static methods
+    ds = [(0, 0), (10, 10), (16000, 400), (400, 16000), (-5, 7), (3, 0), (1, 2)]
+    store["delay/args"] = np.asarray(ds, dtype=np.int64)
+    store["delay/out"] = np.asarray([TemporalSyncNet.delay_score(a, v) for a, v in ds], dtype=np.float64)
+    g = torch.Generator().manual_seed(99)
+    lag_out = []
+    for i, (L_, shift, sr, max_lag) in enumerate([(400, 7, 100.0, 0.5), (400, -13, 100.0, 0.5), (257, 40, 100.0, 0.2), (3, 1, 100.0, 0.5),
+                                                  (64, 5, 16000.0, 0.5), (500, 0, 50.0, 1.0)]):
+        base = torch.randn(L_ + 128, generator=g).numpy()
+        a = base[64:64 + L_].copy()
+        m = base[64 + shift:64 + shift + L_].copy() + 0.05 * torch.randn(L_, generator=g).numpy()
+        m = m[: L_ - (i % 2) * 3]                          # ragged lengths: the shorter one wins
+        store[f"lag/{i}/a"], store[f"lag/{i}/m"] = a.astype(np.float32), m.astype(np.float32)
+        store[f"lag/{i}/args"] = np.asarray([sr, max_lag], dtype=np.float64)
+        lag_out.append(TemporalSyncNet.estimate_av_lag(a, m, sr=sr, max_lag_s=max_lag))
+    store["lag/out"] = np.asarray(lag_out, dtype=np.float64)
+    # initial weights of the module with the sequence path under a fixed seed (construction order :79-94)
+    torch.manual_seed(654)
+    net = TemporalSyncNet(in_dim=768, out_dim=256, use_tcn=True)
+    store["init/rng_after"] = np.float64(float(torch.rand(1)))
+    sd = net.state_dict()
+    store["init/keys"] = np.asarray(list(sd.keys()))
+    store["init/sums"] = np.asarray([float(v.double().sum()) for v in sd.values()], dtype=np.float64)
+    store["init/abs_sums"] = np.asarray([float(v.double().abs().sum()) for v in sd.values()], dtype=np.float64)
+    store["cases"] = np.asarray(json.dumps(SEQ_CASES))
+    np.savez_compressed(HERE / "temporal_seq.npz", **store)
+    print("temporal_seq: oracle-vs-reference worst max-abs-err", worst, "lags", lag_out)
+
+
 def gcn():
     """Graph side of the trainer: build_adj_from_ocr, SimpleGCN.forward and the degree
     pre-training steps (src/training/forensic_trainer.py:25-53,114-132,214-224)."""
@@ -412,7 +486,7 @@ def gcn():
 if __name__ == "__main__":
     part = sys.argv[1] if len(sys.argv) > 1 else "all"
     if part == "all":
-        for p in ("tier_a", "metrics", "tier_b", "temporal", "init_parity", "gcn"):
+        for p in ("tier_a", "metrics", "tier_b", "temporal", "temporal_seq", "init_parity", "gcn"):
             subprocess.check_call([sys.executable, str(Path(__file__).resolve()), p], cwd=str(REPO))
     else:
-        {"tier_a": tier_a, "metrics": metrics, "tier_b": tier_b, "temporal": temporal, "init_parity": init_parity, "gcn": gcn}[part]()
+        {"tier_a": tier_a, "metrics": metrics, "tier_b": tier_b, "temporal": temporal, "temporal_seq": temporal_seq, "init_parity": init_parity, "gcn": gcn}[part]()

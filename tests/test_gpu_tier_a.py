@@ -249,3 +249,47 @@ def test_cosine_schedule_and_criterion_options_in_the_trainer():
         lrs.append(tr.scheduler.get_last_lr()[0])
     want = [2e-5 + (2e-4 - 2e-5) * (1 + math.cos(math.pi * e / 4)) / 2 for e in (1, 2, 3, 4)]
     assert max(abs(a - b) for a, b in zip(lrs, want)) <= 1e-9
+
+
+def test_temporal_sequence_path_matches_reference():
+    """TemporalSyncNet(use_tcn=True).forward on the HIP path vs the reference's outputs (tests/golden/temporal_seq.npz):
+    eval mode (running statistics) and train mode with dropout p=0 (batch statistics + the running-statistics update
+    and num_batches_tracked), four geometries (residual / none at block 0, even kernel, T=1); fp32, 2e-5."""
+    import json
+    from oracle import temporal_ref as T
+    from ultrafnd_git_amd.temporal import TemporalSyncNet
+    g = load_npz("temporal_seq.npz")
+    for name, in_dim, out_dim, hid, layers, k, B, Tn, Dt in json.loads(str(g["cases"])):
+        net = TemporalSyncNet(in_dim=in_dim, out_dim=out_dim, use_tcn=True, tcn_hid=hid, tcn_layers=layers, tcn_kernel=k, dropout=0.0)
+        net.load_state_dict(T.seq_seeded_weights(int(g[f"{name}/weight_seed"]), in_dim, out_dim, hid, layers, k))
+        net = net.to("cuda")
+        ts, vs = torch.from_numpy(g[f"{name}/text_seq"]), torch.from_numpy(g[f"{name}/vis_seq"])
+        net.eval()
+        e_eval = np.abs(net(ts, vs).cpu().numpy() - g[f"{name}/out_eval"]).max()
+        net.train()
+        e_train = np.abs(net(ts.cuda(), vs.cuda()).cpu().numpy() - g[f"{name}/out_train"]).max()
+        sd = net.state_dict()
+        e_stats = max(np.abs(sd[f"tcn.norms.{i}.{s}"].cpu().numpy() - g[f"{name}/after/tcn.norms.{i}.{s}"]).max()
+                      for i in range(layers) for s in ("running_mean", "running_var"))
+        print(f"temporal seq {name}: eval {e_eval:.2e} train {e_train:.2e} running stats {e_stats:.2e}")
+        assert e_eval <= 2e-5 and e_train <= 2e-5 and e_stats <= 2e-5, name
+        assert all(int(sd[f"tcn.norms.{i}.num_batches_tracked"]) == 1 for i in range(layers))
+
+
+def test_temporal_sequence_path_properties():
+    """Size-independent checks at a FakeSV-like shape (B=32 clips x 64 frames, 384+384 channels, default TCN): a clip's
+    eval-mode output does not depend on the other clips of the batch; the module default (train mode, dropout 0.1)
+    draws a fresh mask per call; a wrong channel count is refused as nn.Conv1d refuses it."""
+    from ultrafnd_git_amd.temporal import TemporalSyncNet
+    torch.manual_seed(5)
+    net = TemporalSyncNet(in_dim=768, out_dim=256, use_tcn=True).to("cuda")
+    ts, vs = torch.randn(32, 64, 384, device="cuda"), torch.randn(32, 64, 384, device="cuda")
+    net.eval()
+    full = net(ts, vs)
+    assert full.shape == (32, 256) and torch.isfinite(full).all()
+    assert torch.equal(net(ts[5:9], vs[5:9]), full[5:9])
+    net.train()
+    a, b = net(ts, vs), net(ts, vs)
+    assert not torch.equal(a, b) and torch.isfinite(a).all()
+    with pytest.raises(RuntimeError):
+        net(ts, vs[:, :, :100])

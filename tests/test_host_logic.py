@@ -172,3 +172,28 @@ def test_step_lr_matches_torch():
     for _ in range(10):
         opt.step(); ref.step(); mine.step()
         assert abs(mine.get_last_lr()[0] - ref.get_last_lr()[0]) < 1e-15
+
+
+def test_temporal_sequence_module_init_and_delay_estimators():
+    """TemporalSyncNet(use_tcn=True): the reference's state_dict keys / order and initial weights under the same seed,
+    with the global RNG left where the reference leaves it; delay_score / estimate_av_lag equal the reference's
+    static methods on known inputs, ragged lengths and the < 4 samples case (tests/golden/temporal_seq.npz)."""
+    from tests.helpers import load_npz
+    from ultrafnd_git_amd.temporal import TemporalSyncNet
+    g = load_npz("temporal_seq.npz")
+    torch.manual_seed(654)
+    net = TemporalSyncNet(in_dim=768, out_dim=256, use_tcn=True)
+    assert float(torch.rand(1)) == float(g["init/rng_after"])
+    sd = net.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["init/keys"]]
+    for v, s_, a in zip(sd.values(), g["init/sums"], g["init/abs_sums"]):
+        assert abs(float(v.double().sum()) - s_) <= 1e-9 * max(1.0, a) and abs(float(v.double().abs().sum()) - a) <= 1e-9 * max(1.0, a)
+    assert not any(p.requires_grad for p in net.parameters())
+    with pytest.raises(AssertionError):
+        TemporalSyncNet()(torch.zeros(1, 4, 384), torch.zeros(1, 4, 384))          # use_tcn=False: the reference's assert
+    for (a, v), want in zip(g["delay/args"], g["delay/out"]):
+        assert TemporalSyncNet.delay_score(int(a), int(v)) == float(want)
+    for i, want in enumerate(g["lag/out"]):
+        sr, max_lag = g[f"lag/{i}/args"]
+        got = TemporalSyncNet.estimate_av_lag(g[f"lag/{i}/a"], torch.from_numpy(g[f"lag/{i}/m"]), sr=float(sr), max_lag_s=float(max_lag))
+        assert got == float(want), (i, got, want)

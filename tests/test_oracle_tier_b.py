@@ -52,3 +52,21 @@ def test_temporal_align_matches_reference():
     t, v = torch.from_numpy(z["t"]), torch.from_numpy(z["v"])
     assert np.abs(T.align(w, t, v).numpy() - z["out"]).max() <= 1e-6
     assert np.abs(T.align(w, t[:1], t[:1])[0].numpy() - z["out_self"]).max() <= 1e-6
+
+
+def test_temporal_sequence_path_matches_reference():
+    """oracle/temporal_ref.py::sequence_forward vs the reference's TemporalSyncNet(use_tcn=True).forward in eval and
+    in train mode (dropout p=0), including the BatchNorm running statistics the train-mode call leaves behind
+    (tests/golden/temporal_seq.npz; four geometries: residual / no residual at block 0, even kernel, T=1)."""
+    from oracle import temporal_ref as T
+    g = load_npz("temporal_seq.npz")
+    for n, (name, in_dim, out_dim, hid, layers, k, B, Tn, Dt) in enumerate(json.loads(str(g["cases"]))):
+        w = T.seq_seeded_weights(int(g[f"{name}/weight_seed"]), in_dim, out_dim, hid, layers, k)
+        assert abs(float(sum(x.double().sum() for x in w.values())) - float(g[f"{name}/checksum"])) < 1e-6
+        ts, vs = torch.from_numpy(g[f"{name}/text_seq"]), torch.from_numpy(g[f"{name}/vis_seq"])
+        o_eval, _ = T.sequence_forward(w, ts, vs, layers, k, train=False)
+        o_train, stats = T.sequence_forward(w, ts, vs, layers, k, train=True)
+        assert (o_eval - torch.from_numpy(g[f"{name}/out_eval"])).abs().max().item() <= 2e-5, name
+        assert (o_train - torch.from_numpy(g[f"{name}/out_train"])).abs().max().item() <= 2e-5, name
+        for kk, v in stats.items():
+            assert (v - torch.from_numpy(g[f"{name}/after/{kk}"])).abs().max().item() <= 2e-5, (name, kk)

@@ -54,6 +54,11 @@ class GcnParams(C.Structure):
     _fields_ = [(n, _FP) for n in ("w1", "b1", "w2", "b2")]
 
 
+class TcnLayer(C.Structure):
+    """ufnd_tcn_layer: one Conv1d + BatchNorm1d block of the sequence path."""
+    _fields_ = [(n, _FP) for n in ("w", "b", "gamma", "beta", "running_mean", "running_var")]
+
+
 class GemmLn(C.Structure):
     """ufnd_gemm_ln: the LayerNorm extras of ufnd_gemm_bf16_ln."""
     _fields_ = [("a_stats", _FP), ("colsum", _FP), ("r_stats", _FP), ("r_gamma", _FP), ("r_beta", _FP), ("out_stats", _FP),
@@ -129,6 +134,12 @@ def _declare_encoders(lib: C.CDLL) -> None:
     lib.ufnd_gcn_forward.restype = I
     lib.ufnd_gcn_pretrain_step.argtypes = [P, P, I, C.POINTER(GcnParams), P, P, P, P, P, P, I, I, I, I, F, F, F, I, P, P, P]
     lib.ufnd_gcn_pretrain_step.restype = I
+    lib.ufnd_tcn_weight_ld.argtypes = [I, I]
+    lib.ufnd_tcn_weight_ld.restype = I
+    lib.ufnd_tcn_workspace_floats.argtypes = [I, I, I, I, I]
+    lib.ufnd_tcn_workspace_floats.restype = S
+    lib.ufnd_tcn_forward.argtypes = [P, I, P, I, I, I, C.POINTER(TcnLayer), I, I, I, P, P, I, I, F, F, F, P, P, P, P]
+    lib.ufnd_tcn_forward.restype = I
     lib.ufnd_temporal_weight_ld.argtypes = [I]
     lib.ufnd_temporal_weight_ld.restype = I
     lib.ufnd_temporal_workspace_floats.argtypes = [I, I, I]
