@@ -45,6 +45,38 @@ def gemm_flops_per_step(B: int) -> tuple[float, int]:
     return text + vis, 12 * 4 + 1 + 12 * 4 + 1
 
 
+def gemm_bytes_per_step(B: int) -> float:
+    """Algorithmic HBM bytes of the same launches: bf16 operands in, bf16 rows out; the two residual GEMMs of a layer
+    also read the fp32 residual stream and write it back (fp32 + bf16 + 8 B of statistics per 32 columns)."""
+    H, I3 = 768, 3072
+
+    def g(M, N, K, residual):
+        return 2.0 * (M * K + N * K + M * N) + ((8.0 + 0.25) * M * N if residual else 0.0)
+
+    def layer(M):
+        return g(M, 3 * H, H, False) + g(M, H, H, True) + g(M, I3, H, False) + g(M, H, I3, True)
+    n = B * FRAMES
+    return 12 * layer(B * SEQ_LEN) + 12 * layer(n * 50) + (2.0 * (n * 49 * 3072 + H * 3072) + 4.0 * n * 49 * H) + 2.0 * (n * H + 512 * H) + 4.0 * n * 512
+
+
+def pmc_traffic():
+    """HBM bytes per gemm_bf16_kernel launch from the committed rocprofv3 PMC passes of this same command (newest
+    profiles/r*_pmc_traffic.md: reads = 2 x FETCH_SIZE, writes = WRITE_SIZE, launch-weighted over the GEMM rows).
+    PMC counters cannot be collected from inside the process; None when no summary is present."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.md")))
+    if not files:
+        return None, None
+    tot = n = 0.0
+    for line in open(files[-1]):
+        m = re.match(r"\| gemm_bf16_kernel<[^|]*\| (\d+) \| (\d+) \| ([0-9.]+) \| ([0-9.]+) \|", line)
+        if m:
+            tot += int(m.group(2)) * (float(m.group(3)) + float(m.group(4))) * 1e6
+            n += int(m.group(2))
+    return (tot / n, "profiles/" + os.path.basename(files[-1])) if n else (None, None)
+
+
 def make_batches(B: int, n: int, seed: int, dev: torch.device):
     """Synthetic FakeSV-shaped raw batches, already in HBM."""
     g = torch.Generator().manual_seed(seed)
@@ -190,8 +222,12 @@ def main():
         flops, n_launch = gemm_flops_per_step(B)
         assert launches == n_launch, (launches, n_launch)
         achieved = flops / (gem_ms * 1e-3) / 1e12
+        headline = (SEQ_LEN, FRAMES, B) == (128, 1, 32) and not args.no_fold_ln
+        traffic, traffic_src = pmc_traffic() if headline else (None, None)       # (the PMC passes were taken on the headline run)
         roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
+                "traffic": round(traffic) if traffic else None, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": round(gemm_bytes_per_step(B) / n_launch),
                 "launches_per_step": n_launch, "avg_launch_us": round(gem_ms * 1e3 / n_launch, 2),
                 "gemm_ms_per_step": round(gem_ms, 4), "flops_per_launch_avg": flops / n_launch,
                 "event_marker_us": round(tr.last_marker_us, 2),
