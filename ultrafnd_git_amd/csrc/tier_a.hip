@@ -214,9 +214,14 @@ __global__ __launch_bounds__(256) void coattn_pairs_bwd_kernel(const float* dcat
                                                                const float* qkv, const float* gate, const float* s_in,
                                                                int B, int H, float* dtavu, float* dqkv, float* dg,
                                                                float* dout) {
+  // one wave per 256-column slice of a row (NI waves per row, 4 / NI rows per block): at B = 32 the kernel is a
+  // latency chain, so the slices of a row run side by side; the two row reductions meet in LDS, slices added in order
+  constexpr int RPB = 4 / NI;
+  __shared__ float red[4][8];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + w;
-  if (row >= B) return;
+  const int rsub = w / NI, part = w % NI;
+  const bool live = blockIdx.x * RPB + rsub < B;
+  const int row = live ? blockIdx.x * RPB + rsub : B - 1;
   const float* c = cat + (size_t)row * 16 * H;
   const float* q = qkv + (size_t)row * 9 * H;
   const int QI[3] = {0, 1, 4}, KI[3] = {2, 5, 7}, VI[3] = {3, 6, 8};
@@ -229,32 +234,49 @@ __global__ __launch_bounds__(256) void coattn_pairs_bwd_kernel(const float* dcat
   const f32x4 gt = ld4(gate + (size_t)row * 4), sv = ld4(s_in + (size_t)row * 4);
   // pass 1: the two row reductions of every block
   float r_dg[3] = {0, 0, 0}, r_ds[3] = {0, 0, 0};
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int col = 4 * lane + 256 * i;
+  const int col = 4 * lane + 256 * part;
+  f32x4 dob[3];                                   // dCAT of the three co-attention outputs: used by both passes
+  {
     const f32x4 xs[4] = {ld4(c + col), ld4(c + H + col), ld4(c + 2 * H + col), ld4(c + 3 * H + col)};
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
-      const f32x4 d = G(12 + b, col), val = ld4(q + VI[b] * H + col);
-      r_dg[b] += dot4(d, sv[b] * val - 0.5f * (xs[XS[b]] + xs[YS[b]]));
-      r_ds[b] += dot4(d, val);
+      dob[b] = G(12 + b, col);
+      const f32x4 val = ld4(q + VI[b] * H + col);
+      r_dg[b] = dot4(dob[b], sv[b] * val - 0.5f * (xs[XS[b]] + xs[YS[b]]));
+      r_ds[b] = dot4(dob[b], val);
     }
   }
+#pragma unroll
+  for (int b = 0; b < 3; ++b) { r_dg[b] = wave_sum(r_dg[b]); r_ds[b] = wave_sum(r_ds[b]); }
+  if constexpr (NI > 1) {
+    if (lane == 0) {
+#pragma unroll
+      for (int b = 0; b < 3; ++b) { red[w][b] = r_dg[b]; red[w][3 + b] = r_ds[b]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      float sg = red[rsub * NI][b], ss = red[rsub * NI][3 + b];
+#pragma unroll
+      for (int pp = 1; pp < NI; ++pp) { sg += red[rsub * NI + pp][b]; ss += red[rsub * NI + pp][3 + b]; }
+      r_dg[b] = sg;
+      r_ds[b] = ss;
+    }
+  }
+  if (!live) return;
   const float inv = 1.0f / sqrtf((float)H);
   float dscore[3];
 #pragma unroll
   for (int b = 0; b < 3; ++b) {
-    const float dgate = wave_sum(r_dg[b]);
-    const float ds = gt[b] * wave_sum(r_ds[b]);
+    const float dgate = r_dg[b];
+    const float ds = gt[b] * r_ds[b];
     dscore[b] = ds * sv[b] * (1.0f - sv[b]) * inv;
     r_dg[b] = dgate * gt[b] * (1.0f - gt[b]);  // gradient at the gate's pre-sigmoid output
   }
-  if (lane == 0) st4(dout + (size_t)row * 4, f32x4{r_dg[0], r_dg[1], r_dg[2], 0.f});
+  if (lane == 0 && part == 0) st4(dout + (size_t)row * 4, f32x4{r_dg[0], r_dg[1], r_dg[2], 0.f});
   // pass 2
   float* dq = dqkv + (size_t)row * 9 * H;
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int col = 4 * lane + 256 * i;
+  {
     const f32x4 t = ld4(c + col), a = ld4(c + H + col), v = ld4(c + 2 * H + col), u = ld4(c + 3 * H + col);
     const f32x4 g4 = G(4, col), g5 = G(5, col), g6 = G(6, col), g7 = G(7, col), g8 = G(8, col), g9 = G(9, col),
                 g10 = G(10, col), g11 = G(11, col);
@@ -268,11 +290,10 @@ __global__ __launch_bounds__(256) void coattn_pairs_bwd_kernel(const float* dcat
     d[3] = G(3, col) + g10 + g11;
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
-      const f32x4 dob = G(12 + b, col);
-      const f32x4 half = (0.5f * (1.0f - gt[b])) * dob;
+      const f32x4 half = (0.5f * (1.0f - gt[b])) * dob[b];
       d[XS[b]] += half;
       d[YS[b]] += half;
-      st4(dq + VI[b] * H + col, (gt[b] * sv[b]) * dob);
+      st4(dq + VI[b] * H + col, (gt[b] * sv[b]) * dob[b]);
       st4(dq + QI[b] * H + col, dscore[b] * ld4(q + KI[b] * H + col));
       st4(dq + KI[b] * H + col, dscore[b] * ld4(q + QI[b] * H + col));
     }
@@ -827,7 +848,8 @@ extern "C" int ufnd_fusion_backward(const ufnd_dims* d, const ufnd_fusion_params
     TRY(launch_nn(&n, 1, state, stream));
   }
   // concat / pairwise / co-attention backward (row-wise)
-  NI_DISPATCH(H, coattn_pairs_bwd_kernel, rows, blk, stream, (const float*)w.dcatp, NSPLIT_FUSE0, (const float*)w.cat,
+  const dim3 slices(ufnd_cdiv(B * (H / 256), 4));       // one wave per 256-column slice of a row
+  NI_DISPATCH(H, coattn_pairs_bwd_kernel, slices, blk, stream, (const float*)w.dcatp, NSPLIT_FUSE0, (const float*)w.cat,
               (const float*)w.qkv, (const float*)w.gate, (const float*)w.s, B, H, w.dtavu, w.dqkv, w.dg, w.dout);
   UFND_CHECK_LAUNCH();
   // evidence_proj parameter grads
