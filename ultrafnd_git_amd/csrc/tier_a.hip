@@ -311,6 +311,7 @@ __global__ void gate_param_kernel(const float* evid, const float* dout, int B, i
     const float w00 = p.w0[b][jj * 3], w01 = p.w0[b][jj * 3 + 1], w02 = p.w0[b][jj * 3 + 2], b0 = p.b0[b][jj],
                 w2 = p.w2[b][jj];
     float dw0[3] = {0, 0, 0}, db0 = 0, dw2 = 0;
+#pragma unroll 8
     for (int r = 0; r < B; ++r) {
       const f32x4 ev = ld4(evid + (size_t)r * 4);
       float e[3];
@@ -329,6 +330,7 @@ __global__ void gate_param_kernel(const float* evid, const float* dout, int B, i
     g.w2[b][jj] = dw2;
   }
   if (threadIdx.x == 0) {
+#pragma unroll 8
     for (int r = 0; r < B; ++r) db2 += dout[(size_t)r * 4 + b];
     g.b2[b][0] = db2;
   }
@@ -367,6 +369,7 @@ __global__ void head2_bwd_kernel(const float* dlog, const float* Z, int B, int H
                                  const ufnd_step_state* st, float* dw, float* db) {
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < H; c += gridDim.x * blockDim.x) {
     float s0 = 0, s1 = 0;
+#pragma unroll 8
     for (int r = 0; r < B; ++r) {
       const size_t i = (size_t)r * H + c;
       const float f = gelu_f(Z[i]) * dropout_mul(st, drop_p, layer, (uint32_t)i);
@@ -378,6 +381,7 @@ __global__ void head2_bwd_kernel(const float* dlog, const float* Z, int B, int H
   }
   if (blockIdx.x == 0 && threadIdx.x < 2) {
     float s = 0;
+#pragma unroll 8
     for (int r = 0; r < B; ++r) s += dlog[r * 2 + threadIdx.x];
     db[threadIdx.x] = s;
   }
@@ -561,6 +565,7 @@ __global__ __launch_bounds__(256) void node_param_kernel(const float* df, const 
     int cnt = 0;
     for (int c = threadIdx.x; c < H; c += 256, ++cnt) {
       float s = 0;
+#pragma unroll 8
       for (int r = 0; r < B; ++r) s += df[(size_t)r * 64 + blk] * hh[(size_t)r * H + c];
       da[cnt] = s;
       part += alpha[(size_t)blk * H + c] * s;
@@ -574,6 +579,7 @@ __global__ __launch_bounds__(256) void node_param_kernel(const float* df, const 
       g_gates[(size_t)blk * H + c] = alpha[(size_t)blk * H + c] * (da[cnt] - dotv);
     if (threadIdx.x == 0) {
       float s = 0;
+#pragma unroll 8
       for (int r = 0; r < B; ++r) s += df[(size_t)r * 64 + blk];
       g_thresh[blk] = -s;
     }
@@ -581,11 +587,13 @@ __global__ __launch_bounds__(256) void node_param_kernel(const float* df, const 
     const int c2 = blk - TK;
     for (int c = threadIdx.x; c < H; c += 256) {
       float s = 0;
+#pragma unroll 8
       for (int r = 0; r < B; ++r) s += dlog[r * 2 + c2] * hh[(size_t)r * H + c];
       g_bw[(size_t)c2 * H + c] = s;
     }
     if (threadIdx.x == 0) {
       float s = 0;
+#pragma unroll 8
       for (int r = 0; r < B; ++r) s += dlog[r * 2 + c2];
       g_bb[c2] = s;
     }
@@ -594,6 +602,7 @@ __global__ __launch_bounds__(256) void node_param_kernel(const float* df, const 
     for (int idx = threadIdx.x; idx < trees * leaves * 2; idx += 256) {
       const int c = idx & 1, l = (idx >> 1) % leaves, t = (idx >> 1) / leaves;
       float s = 0;
+#pragma unroll 8
       for (int r = 0; r < B; ++r) {
         float prob = 1.0f;
         for (int k = 0; k < depth; ++k) {
