@@ -164,7 +164,9 @@ def main():
                           use_graph=not args.no_graph, seed=42)
         tr = ForensicTrainer(cfg, cache=synthetic_cache(max(64, 8 * B), seed=1))
         tr.fusion.train(); tr.clf.train()
-        bl = [tr.train_loader.dataset.gather(torch.arange(B, device=dev) % len(tr.train_loader.dataset)) for _ in range(2)]
+        from ultrafnd_git_amd.trainer import IndexedBatch
+        ds = tr.train_loader.dataset            # batches as the loader yields them: row indices of the HBM-resident split
+        bl = [IndexedBatch(ds, (torch.arange(B, device=dev) + k * B) % len(ds)) for k in range(2)]
         for i in range(args.warmup):
             tr.train_step(bl[i % 2])
         torch.cuda.synchronize(dev)

@@ -320,6 +320,22 @@ int ufnd_vit_assemble(const float* patch_emb, const float* cls, const float* pos
 int ufnd_l2norm_frames(const float* e, float* out, int B, int F, int D, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Batch assembly from the device-resident cache: CachedTensorDataset.__getitem__ +
+ * default collate, src/training/forensic_trainer.py:60-83,232-234, and the gnn_Z[global_idx] gather of
+ * _forward_batch :240-252.  For every item, dst row r = src row idx[r] (r < B); rows are row_bytes long
+ * (a multiple of 8, both sides 8-B aligned and densely packed).  One launch for up to 8 tensors.
+ * Indices come from the loader's permutation; an index outside [0, src_rows) is clamped into it.
+ * ---------------------------------------------------------------------------------- */
+#define UFND_GATHER_MAX_ITEMS 8
+typedef struct ufnd_gather_item {
+  const void* src;
+  void* dst;
+  int row_bytes;
+  int64_t src_rows;
+} ufnd_gather_item;
+int ufnd_gather_rows(const int64_t* idx, int B, const ufnd_gather_item* items, int n_items, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * TemporalSyncNet.align, batched          src/core_blocks/temporal_blocks.py:102-140 (+ _cosine :10-13)
  *   text (B,D), visual (B,Dv) fp32 -> out (B,out_dim): W3 GELU(W0 [t, v^, t-v^, t*v^, cos] + b0) + b3
  *   with v^ = visual zero-padded / truncated to D.  w0 is (hidden, 4D+1) stored with row stride

@@ -128,3 +128,29 @@ def test_pipelined_step_equals_plain_step(tmp_path):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     ms, n = tr.measure_gemm_time(batch, steps=1)
     assert n == 2 * 4 + 2 and ms > 0
+
+
+def test_indexed_batches_gather_in_one_launch_and_equal_collated_ones(tmp_path):
+    """The loader's IndexedBatch (row indices of the device-resident split) is the reference's collated dict on demand
+    -- same keys, same tensors -- and the trainer's one-launch gather (ufnd_gather_rows: six cached tensors + gnn_Z)
+    fills the step buffers with exactly what the per-tensor route copies: a step from either is bit-identical."""
+    from ultrafnd_git_amd.trainer import ForensicTrainer, IndexedBatch, TrainConfig, synthetic_cache
+    cache = synthetic_cache(96, seed=3)
+    cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir=str(tmp_path), batch_size=16, device="cuda", seed=7)
+    a, b = ForensicTrainer(cfg, cache=cache), ForensicTrainer(cfg, cache=cache)
+    ds = a.train_loader.dataset
+    lazy = next(iter(a.train_loader))
+    assert type(lazy) is IndexedBatch and "text_features" in lazy and "gnn_feat" not in lazy
+    idx = lazy["index"]
+    full = ds.gather(idx)
+    assert set(full.keys()) <= set(lazy.keys())
+    for k, v in full.items():
+        assert torch.equal(lazy[k], v), k
+    # ragged tail + repeated + out-of-order indices through the kernel
+    for sel in (idx, idx[:5], torch.tensor([3, 3, 0, len(ds) - 1], device="cuda")):
+        ra = a.train_step(IndexedBatch(ds, sel))
+        la = float(ra["loss"])
+        assert torch.equal(ra["y"], ds.y[sel])
+        rb = b.train_step(b.train_loader.dataset.gather(sel))
+        assert la == float(rb["loss"]) and torch.equal(ra["logits"], rb["logits"])
+    assert torch.equal(a.arena.data, b.arena.data)

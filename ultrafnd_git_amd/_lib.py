@@ -54,6 +54,11 @@ class GcnParams(C.Structure):
     _fields_ = [(n, _FP) for n in ("w1", "b1", "w2", "b2")]
 
 
+class GatherItem(C.Structure):
+    """ufnd_gather_item: one cached tensor -> one static batch buffer."""
+    _fields_ = [("src", _FP), ("dst", _FP), ("row_bytes", C.c_int), ("src_rows", C.c_int64)]
+
+
 class TcnLayer(C.Structure):
     """ufnd_tcn_layer: one Conv1d + BatchNorm1d block of the sequence path."""
     _fields_ = [(n, _FP) for n in ("w", "b", "gamma", "beta", "running_mean", "running_var")]
@@ -134,6 +139,8 @@ def _declare_encoders(lib: C.CDLL) -> None:
     lib.ufnd_gcn_forward.restype = I
     lib.ufnd_gcn_pretrain_step.argtypes = [P, P, I, C.POINTER(GcnParams), P, P, P, P, P, P, I, I, I, I, F, F, F, I, P, P, P]
     lib.ufnd_gcn_pretrain_step.restype = I
+    lib.ufnd_gather_rows.argtypes = [P, I, C.POINTER(GatherItem), I, P]
+    lib.ufnd_gather_rows.restype = I
     lib.ufnd_tcn_weight_ld.argtypes = [I, I]
     lib.ufnd_tcn_weight_ld.restype = I
     lib.ufnd_tcn_workspace_floats.argtypes = [I, I, I, I, I]

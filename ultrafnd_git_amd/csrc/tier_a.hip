@@ -994,3 +994,45 @@ extern "C" int ufnd_softmax_ce(const float* logits, const int64_t* labels, int B
   UFND_CHECK_LAUNCH();
   return UFND_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// Batch assembly: CachedTensorDataset.__getitem__ + default collate (forensic_trainer.py:60-83,232-234) and the
+// gnn_Z[global_idx] gather of _forward_batch (:240-252) as ONE launch: row idx[r] of every cached tensor goes
+// straight into the step's static input buffer (the torch route is one gather + one copy per tensor: 13 launches).
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct GatherArgs {
+  const char* src[UFND_GATHER_MAX_ITEMS];
+  char* dst[UFND_GATHER_MAX_ITEMS];
+  int words[UFND_GATHER_MAX_ITEMS];      // row size in 8-byte words
+  long long rows[UFND_GATHER_MAX_ITEMS]; // rows in the source (indices are clamped into it)
+};
+
+__global__ __launch_bounds__(128) void gather_rows_kernel(const int64_t* __restrict__ idx, GatherArgs a) {
+  const int r = blockIdx.x, it = blockIdx.y;
+  long long i = idx[r];
+  i = i < 0 ? 0 : (i < a.rows[it] ? i : a.rows[it] - 1);
+  const uint64_t* s = reinterpret_cast<const uint64_t*>(a.src[it]) + (size_t)i * a.words[it];
+  uint64_t* d = reinterpret_cast<uint64_t*>(a.dst[it]) + (size_t)r * a.words[it];
+  for (int w = threadIdx.x; w < a.words[it]; w += 128) d[w] = s[w];
+}
+}  // namespace
+
+extern "C" int ufnd_gather_rows(const int64_t* idx, int B, const ufnd_gather_item* items, int n_items, void* stream_) {
+  UFND_REQUIRE(idx && items && B >= 1 && n_items >= 1 && n_items <= UFND_GATHER_MAX_ITEMS, "gather_rows: B=%d items=%d", B, n_items);
+  GatherArgs a;
+  for (int i = 0; i < n_items; ++i) {
+    const ufnd_gather_item& t = items[i];
+    UFND_REQUIRE(t.src && t.dst && t.row_bytes >= 8 && t.row_bytes % 8 == 0 && t.src_rows >= 1, "gather_rows: item %d (row_bytes=%d rows=%lld)",
+                 i, t.row_bytes, (long long)t.src_rows);
+    UFND_REQUIRE(ufnd_aligned(t.src, 8) && ufnd_aligned(t.dst, 8), "gather_rows: item %d must be 8-B aligned", i);
+    a.src[i] = static_cast<const char*>(t.src);
+    a.dst[i] = static_cast<char*>(t.dst);
+    a.words[i] = t.row_bytes / 8;
+    a.rows[i] = t.src_rows;
+  }
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(B, n_items), dim3(128), 0, (hipStream_t)stream_, idx, a);
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}

@@ -117,6 +117,55 @@ class CachedTensorDataset(torch.utils.data.Dataset):
         return b
 
 
+class IndexedBatch(dict):
+    """A batch of a device-resident split, named by its row indices (`batch["index"]`).  It is the dict the reference's
+    default collate would build (same keys); a tensor is gathered when it is first asked for.  The trainer never asks:
+    it sends the indices to `ufnd_gather_rows`, which fills the step's static buffers in one launch."""
+    _SRC = {"text_features": "T", "audio_features": "A", "visual_features": "V", "temporal_features": "U", "aux": "AUX",
+            "label": "y", "input_ids": "ids_tok", "attention_mask": "mask_tok", "frames": "frames"}
+
+    def __init__(self, ds: "CachedTensorDataset", idx: torch.Tensor):
+        super().__init__(index=idx)
+        self.ds = ds
+
+    def _lazy(self, k) -> bool:
+        return k in self._SRC and getattr(self.ds, self._SRC[k]) is not None
+
+    def __missing__(self, k):
+        if not self._lazy(k):
+            raise KeyError(k)
+        v = getattr(self.ds, self._SRC[k])[dict.__getitem__(self, "index")]
+        self[k] = v
+        return v
+
+    def __contains__(self, k):
+        return dict.__contains__(self, k) or self._lazy(k)
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def keys(self):
+        return [k for k in self._SRC if self._lazy(k)] + [k for k in dict.keys(self) if k not in self._SRC]
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return len(self.keys())
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+
+def _batch_size(batch) -> int:
+    if type(batch) is IndexedBatch:
+        return int(dict.__getitem__(batch, "index").numel())
+    return int(batch["label"].shape[0])
+
+
 class DeviceBatchLoader:
     """DataLoader(dataset, batch_size, shuffle, drop_last=False) over a device-resident split,
     sharded across data-parallel ranks (DistributedSampler semantics)."""
@@ -142,7 +191,7 @@ class DeviceBatchLoader:
         idx = self._indices().to(self.dataset.T.device)
         self.epoch += 1
         for s in range(0, idx.numel(), self.batch_size):
-            yield self.dataset.gather(idx[s:s + self.batch_size])
+            yield IndexedBatch(self.dataset, idx[s:s + self.batch_size])
 
 
 class ForensicTrainer:
@@ -266,6 +315,21 @@ class ForensicTrainer:
 
     def _load_batch(self, b: dict, batch: Dict[str, torch.Tensor], split: str) -> None:
         """Copy a batch into the static buffers; features come from the cache or from the encoders."""
+        if type(batch) is IndexedBatch and batch.ds.G is not None and not dict.__contains__(batch, "gnn_feat") and \
+                not (self.cfg.encode_inline and "input_ids" in batch):
+            # cached features named by row index: one launch gathers every tensor (and gnn_Z, forensic_trainer.py:240-252)
+            ds, idx = batch.ds, dict.__getitem__(batch, "index")
+            idx = idx.to(self.device, torch.int64).contiguous()
+            pairs = [(ds.T, b["text"]), (ds.A, b["audio"]), (ds.V, b["visual"]), (ds.U, b["temporal"]), (ds.AUX, b["aux"]),
+                     (ds.y, b["label"]), (ds.G, b["gnn"])]
+            items = (L.GatherItem * len(pairs))()
+            for it, (src, dst) in zip(items, pairs):
+                rb = src[0].numel() * src.element_size()
+                if not src.is_contiguous() or src.dtype != dst.dtype or rb != dst[0].numel() * dst.element_size() or src.device != dst.device:
+                    raise RuntimeError(f"cached tensor {tuple(src.shape)} {src.dtype} does not match its batch buffer {tuple(dst.shape)} {dst.dtype}")
+                it.src, it.dst, it.row_bytes, it.src_rows = src.data_ptr(), dst.data_ptr(), rb, src.shape[0]
+            L.check(L.lib().ufnd_gather_rows(idx.data_ptr(), idx.numel(), items, len(pairs), L.stream_ptr(self.device)), "ufnd_gather_rows")
+            return
         if self.cfg.encode_inline and "input_ids" in batch:
             self.prefetch_features(batch, 0)
             for ev in self._feat_ready[0]:
@@ -349,7 +413,7 @@ class ForensicTrainer:
     def train_step(self, batch: Dict[str, torch.Tensor], split: str = "train") -> dict:
         """One iteration of the reference's train loop body (forensic_trainer.py:285-298):
         forward, CE, backward, [all-reduce], clip_grad_norm_, AdamW.step.  Returns device tensors."""
-        B = int(batch["label"].shape[0])
+        B = _batch_size(batch)
         b = self._bufs(B, True)
         self._load_batch(b, batch, split)
         self._fwd_bwd(b, B)
@@ -468,7 +532,7 @@ class ForensicTrainer:
         return out
 
     def _train_step_pipelined(self, batch, next_batch) -> dict:
-        B = int(batch["label"].shape[0])
+        B = _batch_size(batch)
         slot = self._slot
         b = self._bufs(B, True, slot)
         main = torch.cuda.current_stream(self.device)
@@ -559,7 +623,7 @@ class ForensicTrainer:
 
     def _forward_batch(self, batch, split: str) -> Dict[str, torch.Tensor]:
         """Forward only (forensic_trainer.py:238-271); dropout follows the split like .train(is_train)."""
-        B = int(batch["label"].shape[0])
+        B = _batch_size(batch)
         train = split == "train"
         b = self._bufs(B, False)
         self._load_batch(b, batch, split)
@@ -584,7 +648,7 @@ class ForensicTrainer:
             else:
                 o = self._forward_batch(batch, split)
                 out = {"probs": o["probs"], "y": o["y"]}
-                f = self._bufs(int(batch["label"].shape[0]), False)["forensic"]
+                f = self._bufs(_batch_size(batch), False)["forensic"]
                 loss = self.optim.state.float_view("loss")
             # device-side clones; ONE host sync per epoch instead of five per step
             losses.append(loss.clone())
