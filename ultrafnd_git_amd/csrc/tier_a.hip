@@ -139,7 +139,9 @@ __global__ __launch_bounds__(256) void evidence_gate_kernel(const float* cat, in
 #pragma unroll
   for (int b = 0; b < 3; ++b) {
     float o = 0.0f;
-    for (int jj = lane; jj < H; jj += 64) {
+#pragma unroll
+    for (int q4 = 0; q4 < 4 * NI; ++q4) {        // H = 256 NI hidden units, 64 per pass: the parameter loads of all passes fly together
+      const int jj = lane + 64 * q4;
       const float pre = ev.w0[b][jj * 3 + 0] * e[b][0] + ev.w0[b][jj * 3 + 1] * e[b][1] +
                         ev.w0[b][jj * 3 + 2] * e[b][2] + ev.b0[b][jj];
       o += ev.w2[b][jj] * gelu_f(pre);
