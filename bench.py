@@ -134,6 +134,9 @@ def main():
     ap.add_argument("--seq-len", type=int, default=128, help="text length (BASELINE configs[3]: 512 with --batch 128)")
     ap.add_argument("--frames", type=int, default=1, help="frames per sample (BASELINE configs[4]: 8 with --batch 8 per GPU)")
     ap.add_argument("--no-fold-ln", action="store_true", help="one LayerNorm kernel per LayerNorm instead of folding them into the GEMM epilogues")
+    ap.add_argument("--cu-split", type=str, default=None, help="compute units of the text,visual encoder streams, e.g. 192,64 (0 = ordinary streams)")
+    ap.add_argument("--text-tiles", type=str, default=None, help="experiments: GEMM tile ids of the text encoder, e.g. qkv=22,out=16,ffn1=22,ffn2=16")
+    ap.add_argument("--vis-tiles", type=str, default=None, help="experiments: GEMM tile ids of the visual encoder")
     ap.add_argument("--head-only", action="store_true",
                     help="secondary measurement: the reference's actual training mode (cached features, no encoders in the step)")
     args = ap.parse_args()
@@ -185,8 +188,14 @@ def main():
     SEQ_LEN, FRAMES = args.seq_len, args.frames       # (defaults = the headline configuration, BASELINE configs[1])
     tenc = BertTextEncoder(fold_ln=not args.no_fold_ln).to(dev)            # BERT-base geometry, random init (no checkpoints offline)
     venc = ClipVisualEncoder(fold_ln=not args.no_fold_ln).to(dev)          # CLIP ViT-B/32 geometry, random init
+    split = None
+    if args.cu_split and args.cu_split != "0":
+        split = tuple(int(x) for x in args.cu_split.split(","))
     cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir="/tmp/ufnd_bench", batch_size=B, device=str(dev),
-                      use_graph=not args.no_graph, encode_inline=True, seed=42)
+                      use_graph=not args.no_graph, encode_inline=True, seed=42, cu_split=split)
+    for enc, spec in ((tenc, args.text_tiles), (venc, args.vis_tiles)):
+        if spec:
+            enc.tiles = {k: int(v) for k, v in (kv.split("=") for kv in spec.split(","))}
     tsync = TemporalSyncNet(in_dim=768, out_dim=256).to(dev)   # temporal = align(text, visual), as the cache builder does
     tr = ForensicTrainer(cfg, cache=synthetic_cache(64, seed=1), text_encoder=tenc, visual_encoder=venc, temporal_net=tsync)
     tr.fusion.train()

@@ -28,7 +28,7 @@ extern "C" {
 #define UFND_ERR_INVALID 1 /* bad argument: shape, alignment, null pointer */
 #define UFND_ERR_LAUNCH 2  /* HIP launch error */
 
-#define UFND_ABI_VERSION 1
+#define UFND_ABI_VERSION 2
 
 const char* ufnd_last_error(void);
 int ufnd_abi_version(void);
@@ -211,9 +211,10 @@ int ufnd_gemm_bf16(const void* A, const void* W, const float* bias, const float*
                    float* out_f32, int M, int N, int K, int lda, int ldw, int ldr, int ldo, int ldf, int act,
                    void* stream);
 
-/* Same, with an explicit tile configuration (tuning / benchmarking): tile_cfg < 0 = automatic;
- * otherwise an index into the tile table of csrc/gemm_bf16.hip (UFND_GEMM_TILES: block tile, wave
- * grid, LDS ring slots of the A and W operands).  N must be a multiple of the tile width. */
+/* Same, with an explicit tile configuration (the encoders pick tiles per compute-unit partition): tile_cfg < 0 =
+ * automatic; otherwise the id of a tile built into this library (ufnd_gemm_bf16_tile_info; table in
+ * csrc/gemm_bf16_kernel.hpp: block tile, wave grid, LDS ring slots of the A and W operands).  N must be a multiple
+ * of the tile width; any other id is rejected with UFND_ERR_INVALID. */
 int ufnd_gemm_bf16_ex(const void* A, const void* W, const float* bias, const float* residual, void* out_bf16,
                       float* out_f32, int M, int N, int K, int lda, int ldw, int ldr, int ldo, int ldf, int act,
                       int tile_cfg, void* stream);
@@ -243,6 +244,7 @@ typedef struct ufnd_gemm_ln {
   int a_parts, r_parts;
   float a_eps, r_eps;
   int width;
+  int tile_cfg; /* < 0: automatic; otherwise a LayerNorm-aware tile id (ufnd_gemm_bf16_tile_info) */
 } ufnd_gemm_ln;
 int ufnd_gemm_bf16_ln(const void* A, const void* W, const float* bias, const float* residual, void* out_bf16,
                       float* out_f32, int M, int N, int K, int lda, int ldw, int ldr, int ldo, int ldf, int act,
@@ -251,14 +253,12 @@ int ufnd_gemm_bf16_ln(const void* A, const void* W, const float* bias, const flo
  * (0 = the shape's tile has no statistics epilogue). */
 int ufnd_gemm_bf16_stat_parts(int M, int N, int K);
 
-/* Diagnostics: one launch of tile `tile_cfg` built with in-kernel clock stamps.  stamps receives 8 uint64 per
- * block: {s_memtime, s_memrealtime} at kernel entry, after the first K-step has landed, after the K loop, after the
- * last store has drained.  ln != NULL times the LayerNorm-aware kernel of that tile with those extras (bias,
- * residual, out_f32 as in ufnd_gemm_bf16_ln; strides = N).  tools/gemm_stamps.py turns the stamps into per-phase
- * times and the clock the chip held. */
-int ufnd_gemm_bf16_stamps(const void* A, const void* W, void* out_bf16, int M, int N, int K, int tile_cfg,
-                          unsigned long long* stamps, const ufnd_gemm_ln* ln, const float* bias, const float* residual,
-                          float* out_f32, void* stream);
+/* The tile table of this library: ids 0 .. ufnd_gemm_bf16_tile_count()-1; ufnd_gemm_bf16_tile_info returns 1 and the
+ * block tile (rows x columns) of a tile that is built into the library (ln_aware: usable by ufnd_gemm_bf16_ln), 0 for
+ * an id that exists only in the diagnostics library.  Timing ablations, in-kernel stamps and experimental tiles are
+ * NOT reachable through this ABI (they live in libultrafnd_hip_diag.so, csrc/diag/). */
+int ufnd_gemm_bf16_tile_count(void);
+int ufnd_gemm_bf16_tile_info(int tile_cfg, int* bm, int* bn, int* ln_aware);
 
 /* y = LayerNorm(x) * gamma + beta over the last dim (H % 256 == 0, H <= 1024).
  *   x fp32 rows with stride ldx; outputs (M,H) contiguous: bf16 (next GEMM's operand) and/or
@@ -407,6 +407,19 @@ int ufnd_gcn_pretrain_step(const float* x, const float* adj, int ld_adj, const u
                            float* exp_avg_sq, const float* head_w, const float* head_b, float* z, float* workspace, int N,
                            int in_dim, int hid, int out_dim, float dropout_p, float lr, float weight_decay, int step,
                            const ufnd_step_state* state, float* loss, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Compute-unit partitions.  The reference runs its step in program order on one queue
+ * (src/training/forensic_trainer.py:285-298); here the text encoder, the visual encoder and the
+ * head -> exchange -> optimizer chain are concurrent chains on their own HIP streams, each confined to
+ * its share of the 256 CUs so that whole-CU GEMM workgroups of different chains do not displace each other.
+ *   ufnd_stream_create_cu_mask: *stream_out = a hipStream_t restricted to the CUs whose bits are set in
+ *     mask_words (n_words x 32 bits; bit b = logical CU b in the driver's numbering).
+ *   ufnd_device_cu_count: CUs of the current device (256 on MI355X), negative on error.
+ * ---------------------------------------------------------------------------------- */
+int ufnd_stream_create_cu_mask(const uint32_t* mask_words, int n_words, void** stream_out);
+int ufnd_stream_destroy(void* stream);
+int ufnd_device_cu_count(void);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 10
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.ufnd_abi_version() == 1
+    assert lib.ufnd_abi_version() == 2
 
 
 def test_struct_mirrors_match_header_sizes():

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""In-kernel phase times of the bf16 GEMM (GPU box): ufnd_gemm_bf16_stamps writes s_memtime /
+"""In-kernel phase times of the bf16 GEMM (GPU box): ufnd_diag_gemm_bf16_stamps (diagnostics library) writes s_memtime /
 s_memrealtime at kernel entry, first K-step landed, K loop done, stores drained.  Prints, per tile
 configuration and shape, the median over blocks of each phase in us (100 MHz realtime counter), the
 shader clock held inside the K loop, and the first-start -> last-end span of the whole grid.
@@ -10,10 +10,12 @@ import sys
 from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parent))
 import torch
 
 from ultrafnd_git_amd import _lib as L
-from tools.gemm_sweep import SHAPES, TILES
+from _diaglib import check as dcheck, diag
+from gemm_sweep import SHAPES, TILES
 
 
 def main():
@@ -61,7 +63,7 @@ def main():
                 else:
                     ln.r_stats, ln.r_gamma, ln.r_beta, ln.r_parts, ln.out_stats = stats.data_ptr(), vec.data_ptr(), vec.data_ptr(), 24, sto.data_ptr()
             for it in range(12):
-                L.check(L.lib().ufnd_gemm_bf16_stamps(A.data_ptr(), W.data_ptr(), ob.data_ptr(), M, N, K, c, st.data_ptr(),
+                dcheck(diag().ufnd_diag_gemm_bf16_stamps(A.data_ptr(), W.data_ptr(), ob.data_ptr(), M, N, K, c, st.data_ptr(),
                                                       ctypes.byref(ln) if ln is not None else None, vec.data_ptr() if ln is not None else None,
                                                       res.data_ptr() if mode == "rln" else None, of.data_ptr() if mode == "rln" else None,
                                                       L.stream_ptr(A.device)), "stamps")

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Sweep ufnd_gemm_bf16_ex tile configurations over the encoder GEMM shapes (GPU box).
+"""Sweep the tile configurations of the bf16 GEMM (diagnostics library: every tile, ablations) over the encoder GEMM shapes (GPU box).
 Interleaved rounds in ONE process (variants x rounds), median of per-launch HIP-event times minus
 the empty event-pair time, random operands.  Every variant is first checked against an fp32 torch
 matmul of the same bf16 data.   usage: gemm_sweep.py [rounds] [--ablate] [--real] [--cold] [--cfgs=8,22] [--shapes=bert_qkv,...]"""
@@ -8,9 +8,11 @@ import sys
 from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parent))
 import torch
 
 from ultrafnd_git_amd import _lib as L
+from _diaglib import check as dcheck, diag
 
 DEV = "cuda"
 SHAPES = [("bert_qkv", 4096, 2304, 768), ("bert_out", 4096, 768, 768), ("bert_ffn1", 4096, 3072, 768),
@@ -70,11 +72,11 @@ def run(cfg, A, W, bias, ob, M, N, K, name=None):
         assert rc == 0, rc
         return
     if res:
-        L.check(L.lib().ufnd_gemm_bf16_ex(A.data_ptr(), W.data_ptr(), bias.data_ptr(), RES.data_ptr(), None, OF.data_ptr(), M, N, K,
-                                          K, K, N, 0, N, act, cfg, L.stream_ptr(A.device)), "gemm_ex")
+        dcheck(diag().ufnd_diag_gemm_bf16_ex(A.data_ptr(), W.data_ptr(), bias.data_ptr(), RES.data_ptr(), None, OF.data_ptr(), M, N, K,
+                                             K, K, N, 0, N, act, cfg, L.stream_ptr(A.device)), "gemm_ex")
     else:
-        L.check(L.lib().ufnd_gemm_bf16_ex(A.data_ptr(), W.data_ptr(), bias.data_ptr(), None, ob.data_ptr(), None, M, N, K, K, K, 0,
-                                          N, 0, act, cfg, L.stream_ptr(A.device)), "gemm_ex")
+        dcheck(diag().ufnd_diag_gemm_bf16_ex(A.data_ptr(), W.data_ptr(), bias.data_ptr(), None, ob.data_ptr(), None, M, N, K, K, K, 0,
+                                             N, 0, act, cfg, L.stream_ptr(A.device)), "gemm_ex")
 
 
 def empty_pair_ms():

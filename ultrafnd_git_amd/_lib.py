@@ -67,10 +67,17 @@ class TcnLayer(C.Structure):
 class GemmLn(C.Structure):
     """ufnd_gemm_ln: the LayerNorm extras of ufnd_gemm_bf16_ln."""
     _fields_ = [("a_stats", _FP), ("colsum", _FP), ("r_stats", _FP), ("r_gamma", _FP), ("r_beta", _FP), ("out_stats", _FP),
-                ("a_parts", C.c_int), ("r_parts", C.c_int), ("a_eps", C.c_float), ("r_eps", C.c_float), ("width", C.c_int)]
+                ("a_parts", C.c_int), ("r_parts", C.c_int), ("a_eps", C.c_float), ("r_eps", C.c_float), ("width", C.c_int),
+                ("tile_cfg", C.c_int)]
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        if "tile_cfg" not in kw:
+            self.tile_cfg = -1
 
 
 STEP_STATE_BYTES = C.sizeof(StepState)
+ABI_VERSION = 2
 
 _lib: Optional[C.CDLL] = None
 
@@ -110,7 +117,6 @@ def _declare_encoders(lib: C.CDLL) -> None:
         "ufnd_cast_bf16": [P, P, S, P],
         "ufnd_gemm_bf16": [P] * 6 + [I] * 9 + [P],
         "ufnd_gemm_bf16_ex": [P] * 6 + [I] * 10 + [P],
-        "ufnd_gemm_bf16_stamps": [P, P, P, I, I, I, I, P, C.POINTER(GemmLn), P, P, P, P],
         "ufnd_layernorm": [P, I, P, P, P, P, I, I, F, P],
         "ufnd_attention_bf16": [P, P, P, I, I, I, P],
         "ufnd_bert_embed": [P] * 8 + [I, I, I, I, F, P],
@@ -122,6 +128,11 @@ def _declare_encoders(lib: C.CDLL) -> None:
         "ufnd_vit_assemble": [P] * 8 + [I, I, I, F, P],
         "ufnd_gemm_bf16_ln": [P] * 6 + [I] * 9 + [C.POINTER(GemmLn), P],
         "ufnd_gemm_bf16_stat_parts": [I, I, I],
+        "ufnd_gemm_bf16_tile_count": [],
+        "ufnd_gemm_bf16_tile_info": [I, C.POINTER(I), C.POINTER(I), C.POINTER(I)],
+        "ufnd_stream_create_cu_mask": [C.POINTER(C.c_uint32), I, C.POINTER(P)],
+        "ufnd_stream_destroy": [P],
+        "ufnd_device_cu_count": [],
         "ufnd_l2norm_frames": [P, P, I, I, I, P],
         "ufnd_field_mean_l2": [P, P, P, I, I, I, P],
         "ufnd_temporal_align": [P] * 8 + [I] * 5 + [P],
@@ -163,7 +174,7 @@ def lib() -> C.CDLL:
                 "This package has no CPU fallback.")
         l = C.CDLL(str(LIB_PATH))
         _declare(l)
-        if l.ufnd_abi_version() != 1:
+        if l.ufnd_abi_version() != ABI_VERSION:
             raise UltrafndHipError("libultrafnd_hip.so ABI version mismatch; rebuild")
         _lib = l
     return _lib

@@ -1,9 +1,13 @@
-"""Build libultrafnd_hip.so in-tree with hipcc for gfx950 (MI355X).
+"""Build the HIP libraries in-tree with hipcc for gfx950 (MI355X).
 
-    python -m ultrafnd_git_amd.build [--verbose]
+    python -m ultrafnd_git_amd.build [--verbose] [--force] [--diag]
 
-hipcc cross-compiles without a GPU.  The .so is git-ignored but travels to the GPU box with
-the working tree.  Nothing here imports torch.
+  libultrafnd_hip.so        the product: every source of csrc/*.hip (include/ultrafnd_hip.h)
+  libultrafnd_hip_diag.so   diagnostics only (csrc/diag/*.hip, built with -DUFND_DIAG): timing ablations, in-kernel
+                            stamps, every experimental GEMM tile, the placement probe.  tools/ load it; the package never does.
+
+hipcc cross-compiles without a GPU.  The .so files are git-ignored but travel to the GPU box with the working
+tree.  Sources are compiled to objects in parallel, then linked.  Nothing here imports torch.
 """
 from __future__ import annotations
 
@@ -11,12 +15,14 @@ import hashlib
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libultrafnd_hip.so"
-STAMP = PKG / ".libultrafnd_hip.stamp"
+DIAG_LIB = PKG / "libultrafnd_hip_diag.so"
+OBJ = PKG / "build"
 ARCH = "gfx950"
 
 
@@ -24,35 +30,74 @@ def sources():
     return sorted(CSRC.glob("*.hip"))
 
 
-def _digest() -> str:
+def diag_sources():
+    return sorted((CSRC / "diag").glob("*.hip")) + [CSRC / "api.hip"]
+
+
+def _defs() -> list:
+    return ["-D" + d for d in os.environ.get("UFND_BUILD_DEFS", "").split(",") if d]      # experiments: extra -D switches
+
+
+def _digest(extra: str) -> str:
     h = hashlib.sha256()
-    for f in sorted(list(CSRC.glob("*")) + [PKG.parent / "include" / "ultrafnd_hip.h"]):
+    h.update(extra.encode())
+    h.update(" ".join(_defs()).encode())       # an experimental -D build is never mistaken for the current one
+    files = sorted(list(CSRC.glob("*")) + list((CSRC / "diag").glob("*")) + [PKG.parent / "include" / "ultrafnd_hip.h"])
+    for f in files:
         if f.is_file():
             h.update(f.name.encode())
             h.update(f.read_bytes())
     return h.hexdigest()
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
-    dig = _digest()
-    if not force and LIB.exists() and STAMP.exists() and STAMP.read_text().strip() == dig:
-        return LIB
+def _compile(src: Path, tag: str, flags: list, verbose: bool) -> Path:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-pass-failed", "-o", str(LIB)] + [str(s) for s in sources()]
-    if os.environ.get("UFND_BUILD_DEFS"):          # experiments: extra -D switches (e.g. UFND_GEMM_WT=1)
-        cmd[1:1] = ["-D" + d for d in os.environ["UFND_BUILD_DEFS"].split(",")]
+    obj = OBJ / f"{tag}_{src.stem}.o"
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-c", str(src), "-o", str(obj)] + flags + _defs()
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))
-    r = subprocess.run(cmd, cwd=str(CSRC), capture_output=not verbose, text=True)
+    r = subprocess.run(cmd, cwd=str(src.parent), capture_output=not verbose, text=True)
     if r.returncode != 0:
         sys.stderr.write((r.stdout or "") + (r.stderr or ""))
-        raise RuntimeError("hipcc failed building libultrafnd_hip.so")
-    STAMP.write_text(dig)
-    return LIB
+        raise RuntimeError(f"hipcc failed on {src.name}")
+    return obj
+
+
+def _link(objs: list, lib: Path) -> None:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    r = subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(lib)] + [str(o) for o in objs],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write((r.stdout or "") + (r.stderr or ""))
+        raise RuntimeError(f"link of {lib.name} failed")
+
+
+def _build_one(lib: Path, srcs: list, tag: str, flags: list, force: bool, verbose: bool) -> Path:
+    stamp = PKG / f".{lib.stem}.stamp"
+    dig = _digest(tag)
+    if not force and lib.exists() and stamp.exists() and stamp.read_text().strip() == dig:
+        return lib
+    OBJ.mkdir(exist_ok=True)
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(lambda s: _compile(s, tag, flags, verbose), srcs))
+    _link(objs, lib)
+    stamp.write_text(dig)
+    return lib
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    return _build_one(LIB, sources(), "prod", [], force, verbose)
+
+
+def build_diag(force: bool = False, verbose: bool = False) -> Path:
+    # api.hip is compiled again with renamed exports: the diagnostics library is self-contained
+    flags = ["-DUFND_DIAG=1", "-Dufnd_last_error=ufnd_diag_last_error", "-Dufnd_abi_version=ufnd_diag_abi_version"]
+    return _build_one(DIAG_LIB, diag_sources(), "diag", flags, force, verbose)
 
 
 if __name__ == "__main__":
     p = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv)
     print(p)
+    if "--diag" in sys.argv:
+        print(build_diag(force="--force" in sys.argv, verbose="--verbose" in sys.argv))

@@ -1,0 +1,47 @@
+// Diagnostics build of the bf16 GEMM (libultrafnd_hip_diag.so; never loaded by the product package): every tile of
+// the table, the timing-only ablation kernels (no MFMA / no in-loop DMA: results are garbage), the in-kernel stamps
+// build and the UFND_GEMM_FORCE_CFG override.  Used by tools/gemm_sweep.py and tools/gemm_stamps.py.
+#define UFND_DIAG 1
+#include "../gemm_bf16_kernel.hpp"
+
+// out = act(A W^T + bias) + residual with an explicit tile; tile_cfg + 100 / + 200 select the timing-only ablations.
+extern "C" int ufnd_diag_gemm_bf16_ex(const void* A, const void* W, const float* bias, const float* residual, void* out_bf16,
+                                      float* out_f32, int M, int N, int K, int lda, int ldw, int ldr, int ldo, int ldf, int act,
+                                      int tile_cfg, void* stream_) {
+  UFND_REQUIRE(A && W && (out_bf16 || out_f32), "diag gemm: null operand");
+  UFND_REQUIRE(M >= 1 && N >= 64 && K >= 64 && N % 64 == 0 && K % 64 == 0, "diag gemm: M=%d N=%d K=%d", M, N, K);
+  GemmArgs a{(const __bf16*)A, (const __bf16*)W, bias, residual, (__bf16*)out_bf16, out_f32, M, N, K, lda, ldw, ldr, ldo, ldf, act, 0, 0, nullptr};
+  int mode = 0, cfg = tile_cfg < 0 ? auto_cfg(M, N, K) : tile_cfg;
+  if (cfg >= 200) { mode = 2; cfg -= 200; } else if (cfg >= 100) { mode = 1; cfg -= 100; }
+  UFND_REQUIRE(cfg < kNumTiles, "diag gemm: unknown tile config %d", cfg);
+  UFND_REQUIRE(N % kTiles[cfg].bn == 0, "diag gemm: tile config %d needs N %% %d == 0", cfg, kTiles[cfg].bn);
+  int rc = launch_cfg(cfg, mode, a, (hipStream_t)stream_);
+  if (rc != UFND_OK) return rc;
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}
+
+// One launch of tile `tile_cfg` built with in-kernel clock stamps.  stamps receives 8 uint64 per block: {s_memtime,
+// s_memrealtime} at kernel entry, after the first K-step has landed, after the K loop, after the last store has drained.
+// ln != NULL times the LayerNorm-aware kernel of that tile (bias, residual, out_f32 as in ufnd_gemm_bf16_ln; strides = N).
+extern "C" int ufnd_diag_gemm_bf16_stamps(const void* A, const void* W, void* out_bf16, int M, int N, int K, int tile_cfg,
+                                     unsigned long long* stamps, const ufnd_gemm_ln* ln, const float* bias, const float* residual,
+                                     float* out_f32, void* stream_) {
+  UFND_REQUIRE(A && W && out_bf16 && stamps, "gemm_bf16_stamps: null operand");
+  UFND_REQUIRE(M >= 1 && N >= 64 && K >= 64 && N % 64 == 0 && K % 64 == 0, "gemm_bf16_stamps: M=%d N=%d K=%d", M, N, K);
+  UFND_REQUIRE(tile_cfg >= 0 && tile_cfg < kNumTiles && N % kTiles[tile_cfg].bn == 0, "gemm_bf16_stamps: tile config %d", tile_cfg);
+  GemmArgs a{(const __bf16*)A, (const __bf16*)W, bias, residual, (__bf16*)out_bf16, out_f32, M, N, K, K, K, N, N, N, 0, 0, 0, stamps};
+  int abl = 3;
+  if (ln) {      // the LayerNorm-aware kernel of this tile, same extras as ufnd_gemm_bf16_ln (unchecked: diagnostics)
+    UFND_REQUIRE(kTiles[tile_cfg].lnx, "gemm_bf16_stamps: tile %d has no LayerNorm-aware kernel", tile_cfg);
+    a.a_stats = ln->a_stats; a.colsum = ln->colsum; a.r_stats = ln->r_stats; a.r_gamma = ln->r_gamma; a.r_beta = ln->r_beta;
+    a.out_stats = ln->out_stats; a.a_parts = ln->a_parts; a.r_parts = ln->r_parts; a.a_eps = ln->a_eps; a.r_eps = ln->r_eps;
+    a.inv_h = 1.0f / (float)ln->width;
+    abl = 5;
+  }
+  int rc = launch_cfg(tile_cfg, abl, a, (hipStream_t)stream_);
+  if (rc != UFND_OK) return rc;
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}
+

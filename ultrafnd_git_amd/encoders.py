@@ -49,6 +49,7 @@ class _EncoderBase(nn.Module):
 
     def __init__(self):
         super().__init__()
+        self.tiles = {}
         self._w: "OrderedDict[str, torch.Tensor]" = OrderedDict()
         self._packed: Optional[dict] = None
         self._bufs: Dict[Tuple, dict] = {}
@@ -87,18 +88,22 @@ class _EncoderBase(nn.Module):
             raise L.UltrafndHipError(f"{type(self).__name__} runs on a HIP device only: call .to('cuda') (no CPU fallback)")
 
     # ---- thin wrappers over the C ABI
-    def _gemm(self, A, W, bias, out_bf16=None, out_f32=None, residual=None, act=ACT_NONE, M=None):
+    # GEMM tile per Linear ("qkv", "out", "ffn1", "ffn2"): -1 = the library's own choice for the shape.  Set by the
+    # trainer when the encoder runs on a compute-unit partition (a launch wants about one tile per CU it may use).
+    tiles: Dict[str, int] = {}
+
+    def _gemm(self, A, W, bias, out_bf16=None, out_f32=None, residual=None, act=ACT_NONE, M=None, which=None):
         M = A.shape[0] if M is None else M
         N, K = W.shape
-        L.check(L.lib().ufnd_gemm_bf16(A.data_ptr(), W.data_ptr(), L.ptr(bias), L.ptr(residual), L.ptr(out_bf16),
-                                       L.ptr(out_f32), M, N, K, A.stride(0), W.stride(0),
-                                       residual.stride(0) if residual is not None else 0,
-                                       out_bf16.stride(0) if out_bf16 is not None else 0,
-                                       out_f32.stride(0) if out_f32 is not None else 0, act,
-                                       L.stream_ptr(A.device)), "ufnd_gemm_bf16")
+        L.check(L.lib().ufnd_gemm_bf16_ex(A.data_ptr(), W.data_ptr(), L.ptr(bias), L.ptr(residual), L.ptr(out_bf16),
+                                          L.ptr(out_f32), M, N, K, A.stride(0), W.stride(0),
+                                          residual.stride(0) if residual is not None else 0,
+                                          out_bf16.stride(0) if out_bf16 is not None else 0,
+                                          out_f32.stride(0) if out_f32 is not None else 0, act, self.tiles.get(which, -1),
+                                          L.stream_ptr(A.device)), "ufnd_gemm_bf16_ex")
 
     def _gemm_ln(self, A, W, bias, out_bf16=None, out_f32=None, residual=None, act=ACT_NONE, a_stats=None, colsum=None,
-                 r_stats=None, r_gamma=None, r_beta=None, out_stats=None, eps=1e-5):
+                 r_stats=None, r_gamma=None, r_beta=None, out_stats=None, eps=1e-5, which=None):
         """ufnd_gemm_bf16_ln: a_stats / r_stats / out_stats are (M, parts, 2) fp32 tensors."""
         M = A.shape[0]
         N, K = W.shape
@@ -110,6 +115,7 @@ class _EncoderBase(nn.Module):
         ln.r_parts = r_stats.shape[1] if r_stats is not None else 0
         ln.a_eps = ln.r_eps = eps
         ln.width = self.hidden
+        ln.tile_cfg = self.tiles.get(which, -1)
         import ctypes
         L.check(L.lib().ufnd_gemm_bf16_ln(A.data_ptr(), W.data_ptr(), L.ptr(bias), L.ptr(residual), L.ptr(out_bf16),
                                           L.ptr(out_f32), M, N, K, A.stride(0), W.stride(0),
@@ -242,12 +248,12 @@ class BertTextEncoder(_EncoderBase):
         if "st1" in b:
             return self._layers_folded(p, v, M, attn)
         for ly in p["layers"]:
-            self._gemm(v["xb"], ly["wqkv"], ly["bqkv"], out_bf16=v["qkv"])
+            self._gemm(v["xb"], ly["wqkv"], ly["bqkv"], out_bf16=v["qkv"], which="qkv")
             attn(v["qkv"], v["ctx"])
-            self._gemm(v["ctx"], ly["wo"], ly["bo"], out_f32=v["y"], residual=v["xf"])
+            self._gemm(v["ctx"], ly["wo"], ly["bo"], out_f32=v["y"], residual=v["xf"], which="out")
             self._ln(v["y"], H, ly["g1"], ly["b1"], v["x1b"], v["x1f"], M, H, self.eps)
-            self._gemm(v["x1b"], ly["w1"], ly["bi"], out_bf16=v["h"], act=ACT_GELU)
-            self._gemm(v["h"], ly["w2"], ly["b2"], out_f32=v["y"], residual=v["x1f"])
+            self._gemm(v["x1b"], ly["w1"], ly["bi"], out_bf16=v["h"], act=ACT_GELU, which="ffn1")
+            self._gemm(v["h"], ly["w2"], ly["b2"], out_f32=v["y"], residual=v["x1f"], which="ffn2")
             self._ln(v["y"], H, ly["g2"], ly["b2n"], v["xb"], v["xf"], M, H, self.eps)
 
     def _layers_folded(self, p, b, M, attn) -> None:
@@ -258,18 +264,18 @@ class BertTextEncoder(_EncoderBase):
         prev = None
         for ly in p["layers"]:
             if prev is None:      # layer 0 consumes the embeddings' own (materialised) LayerNorm
-                self._gemm(b["xb"], ly["wqkv"], ly["bqkv"], out_bf16=b["qkv"])
+                self._gemm(b["xb"], ly["wqkv"], ly["bqkv"], out_bf16=b["qkv"], which="qkv")
             else:
-                self._gemm_ln(b["y2b"], ly["wqkvf"], ly["bqkvf"], out_bf16=b["qkv"], a_stats=b["st2"], colsum=ly["csqkv"], eps=eps)
+                self._gemm_ln(b["y2b"], ly["wqkvf"], ly["bqkvf"], out_bf16=b["qkv"], a_stats=b["st2"], colsum=ly["csqkv"], eps=eps, which="qkv")
             attn(b["qkv"], b["ctx"])
             if prev is None:
-                self._gemm_ln(b["ctx"], ly["wo"], ly["bo"], out_f32=y1, out_bf16=b["y1b"], residual=b["xf"], out_stats=b["st1"], eps=eps)
+                self._gemm_ln(b["ctx"], ly["wo"], ly["bo"], out_f32=y1, out_bf16=b["y1b"], residual=b["xf"], out_stats=b["st1"], eps=eps, which="out")
             else:
                 self._gemm_ln(b["ctx"], ly["wo"], ly["bo"], out_f32=y1, out_bf16=b["y1b"], residual=y2, r_stats=b["st2"],
-                              r_gamma=prev["g2"], r_beta=prev["b2n"], out_stats=b["st1"], eps=eps)
-            self._gemm_ln(b["y1b"], ly["w1f"], ly["bif"], out_bf16=b["h"], act=ACT_GELU, a_stats=b["st1"], colsum=ly["cs1"], eps=eps)
+                              r_gamma=prev["g2"], r_beta=prev["b2n"], out_stats=b["st1"], eps=eps, which="out")
+            self._gemm_ln(b["y1b"], ly["w1f"], ly["bif"], out_bf16=b["h"], act=ACT_GELU, a_stats=b["st1"], colsum=ly["cs1"], eps=eps, which="ffn1")
             self._gemm_ln(b["h"], ly["w2"], ly["b2"], out_f32=y2, out_bf16=b["y2b"], residual=y1, r_stats=b["st1"],
-                          r_gamma=ly["g1"], r_beta=ly["b1"], out_stats=b["st2"], eps=eps)
+                          r_gamma=ly["g1"], r_beta=ly["b1"], out_stats=b["st2"], eps=eps, which="ffn2")
             prev = ly
         self._ln(y2, H, prev["g2"], prev["b2n"], b["xb"], b["xf"], M, H, eps)      # last_hidden_state is materialised once
 
@@ -453,23 +459,23 @@ class ClipVisualEncoder(_EncoderBase):
             # st* the row statistics its LayerNorms need (module docstring)
             eps, stA = self.eps, b["st0"]
             for ly in p["layers"]:
-                self._gemm_ln(b["hb"], ly["wqkvf"], ly["bqkvf"], out_bf16=b["qkv"], a_stats=stA, colsum=ly["csqkv"], eps=eps)
+                self._gemm_ln(b["hb"], ly["wqkvf"], ly["bqkvf"], out_bf16=b["qkv"], a_stats=stA, colsum=ly["csqkv"], eps=eps, which="qkv")
                 self._attn(b["qkv"], None, b["ctx"], N, T, self.heads)
-                self._gemm_ln(b["ctx"], ly["wo"], ly["bo"], out_f32=b["xf"], out_bf16=b["hb"], residual=b["xf"], out_stats=b["st1"], eps=eps)
-                self._gemm_ln(b["hb"], ly["w1f"], ly["bif"], out_bf16=b["m"], act=ACT_QUICK_GELU, a_stats=b["st1"], colsum=ly["cs1"], eps=eps)
-                self._gemm_ln(b["m"], ly["w2"], ly["b2"], out_f32=b["xf"], out_bf16=b["hb"], residual=b["xf"], out_stats=b["st2"], eps=eps)
+                self._gemm_ln(b["ctx"], ly["wo"], ly["bo"], out_f32=b["xf"], out_bf16=b["hb"], residual=b["xf"], out_stats=b["st1"], eps=eps, which="out")
+                self._gemm_ln(b["hb"], ly["w1f"], ly["bif"], out_bf16=b["m"], act=ACT_QUICK_GELU, a_stats=b["st1"], colsum=ly["cs1"], eps=eps, which="ffn1")
+                self._gemm_ln(b["m"], ly["w2"], ly["b2"], out_f32=b["xf"], out_bf16=b["hb"], residual=b["xf"], out_stats=b["st2"], eps=eps, which="ffn2")
                 stA = b["st2"]
             self._ln(b["xf"], T * H, w[V + "post_layernorm.weight"], w[V + "post_layernorm.bias"], b["pooled"], None, N, H, self.eps)
             self._gemm(b["pooled"], p["wproj"], None, out_f32=b["e"])
             return b["e"], b
         for ly in p["layers"]:
             self._ln(b["xf"], H, ly["g1"], ly["b1"], b["hb"], None, M, H, self.eps)
-            self._gemm(b["hb"], ly["wqkv"], ly["bqkv"], out_bf16=b["qkv"])
+            self._gemm(b["hb"], ly["wqkv"], ly["bqkv"], out_bf16=b["qkv"], which="qkv")
             self._attn(b["qkv"], None, b["ctx"], N, T, self.heads)
-            self._gemm(b["ctx"], ly["wo"], ly["bo"], out_f32=b["xf"], residual=b["xf"])
+            self._gemm(b["ctx"], ly["wo"], ly["bo"], out_f32=b["xf"], residual=b["xf"], which="out")
             self._ln(b["xf"], H, ly["g2"], ly["b2n"], b["hb"], None, M, H, self.eps)
-            self._gemm(b["hb"], ly["w1"], ly["bi"], out_bf16=b["m"], act=ACT_QUICK_GELU)
-            self._gemm(b["m"], ly["w2"], ly["b2"], out_f32=b["xf"], residual=b["xf"])
+            self._gemm(b["hb"], ly["w1"], ly["bi"], out_bf16=b["m"], act=ACT_QUICK_GELU, which="ffn1")
+            self._gemm(b["m"], ly["w2"], ly["b2"], out_f32=b["xf"], residual=b["xf"], which="ffn2")
         # post-LN on the CLS rows (row stride T*H), bias-free projection
         self._ln(b["xf"], T * H, w[V + "post_layernorm.weight"], w[V + "post_layernorm.bias"], b["pooled"], None, N, H, self.eps)
         self._gemm(b["pooled"], p["wproj"], None, out_f32=b["e"])

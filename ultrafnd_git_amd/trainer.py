@@ -70,6 +70,9 @@ class TrainConfig:
     class_weighting: bool = False  # CE weights 0.5 * total / count(class) from the cache's labels
     use_cosine: bool = False       # CosineAnnealingLR(T_max = epochs, eta_min = lr * min_lr_scale) instead of StepLR(3, 0.7)
     min_lr_scale: float = 0.1
+    # compute units of the (text encoder, visual encoder) streams when the encoders run inside the step (streams.py);
+    # None = ordinary streams.  The head -> exchange -> optimizer chain keeps the whole chip at high priority.
+    cu_split: Optional[Tuple[int, int]] = None
 
 
 class CachedTensorDataset(torch.utils.data.Dataset):
@@ -435,9 +438,18 @@ class ForensicTrainer:
                 "text_out": torch.empty(B, 768, dtype=torch.float32, device=dev),
                 "vis_out": torch.empty(B, 512, dtype=torch.float32, device=dev), "g_text": None, "g_vis": None}
         if self._enc_streams is None:
-            # (default priorities: a high-priority text stream bought 0.5 % at one GPU and cost 2x under data
-            #  parallelism, where the all-reduce of step i must get CUs while the encoders of step i+1 run)
-            self._enc_streams = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
+            split = self.cfg.cu_split
+            if os.environ.get("UFND_CU_SPLIT"):          # experiments: "192,64" / "0" = off
+                v = [int(x) for x in os.environ["UFND_CU_SPLIT"].split(",")]
+                split = tuple(v) if len(v) == 2 and v[0] > 0 else None
+            if split:
+                from .streams import MaskedStream, partition_bits
+                bt, bv = partition_bits(split)
+                self._enc_streams = (MaskedStream(self.device, bt), MaskedStream(self.device, bv))
+            else:
+                # (default priorities: a high-priority text stream bought 0.5 % at one GPU and cost 2x under data
+                #  parallelism, where the all-reduce of step i must get CUs while the encoders of step i+1 run)
+                self._enc_streams = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
         return self._enc_bufs[key]
 
     def _encode_text(self, e: dict) -> None:
