@@ -143,6 +143,23 @@ int ufnd_fusion_backward(const ufnd_dims* d, const ufnd_fusion_params* p, const 
                          int ld_dfused, const float* d_logits, const ufnd_step_state* state, void* stream,
                          void* side_stream, int join);
 
+/* The same backward in two phases, for a gradient exchange that overlaps backward (data parallel; the reference
+ * step is single-process, forensic_trainer.py:285-298).  The flat gradient arena is laid out in gradient-ready
+ * order [classifier | fuse_mlp | co-attention | projections]:
+ *   UFND_BWD_FUSE_MLP  d_fused -> fuse_mlp.3 -> fuse_mlp.0: their dW / db (incl. the 33.5 MB fuse_mlp.0.weight
+ *                      gradient, 2/3 of all gradient bytes) are complete when this call's work has run -- the
+ *                      caller starts all-reducing [classifier | fuse_mlp] while
+ *   UFND_BWD_REST      computes everything else (co-attention, stacked q/k/v, projections).
+ * FUSE_MLP followed by REST writes bit-identical gradients to UFND_BWD_ALL (= ufnd_fusion_backward). */
+#define UFND_BWD_ALL 0
+#define UFND_BWD_FUSE_MLP 1
+#define UFND_BWD_REST 2
+int ufnd_fusion_backward_phase(const ufnd_dims* d, const ufnd_fusion_params* p, const ufnd_fusion_params* g,
+                               const float* text, const float* audio, const float* visual, const float* temporal,
+                               const float* gnn, int B, int train, float* workspace, const float* d_fused,
+                               int ld_dfused, const float* d_logits, const ufnd_step_state* state, void* stream,
+                               void* side_stream, int join, int phase);
+
 /* ------------------------------------------------------------------------------------
  * DeepTruthClassifier.forward                   src/models/fusion/deep_truth_classifier.py:148-171
  *   fused (B,hidden) stride ld_fused; aux (B,aux_dim) or NULL when aux_dim == 0.

@@ -1,0 +1,171 @@
+"""Child of the data-parallel GPU tests (tests/test_gpu_dp.py), run under `python -m torch.distributed.run`.
+
+  --mode force1   world 1, backend nccl (= RCCL), UFND_FORCE_REDUCE=1: the bucketed, overlapped gradient exchange is
+                  live on one GPU.  Plain and pipelined steps through ForensicTrainer must leave the parameter arena
+                  bit-identical to the same steps without any exchange (a one-rank sum is the identity).
+  --mode world2   two ranks sharing cuda:0 over gloo (gradients staged through pinned host memory: a test seam, the
+                  product exchange is RCCL): sharded batches + summed gradients + 1/world == the single-process
+                  full-batch step; then fit() / test() with sharded loaders, gathered metrics, the rank-0 checkpoint.
+Prints one JSON line on rank 0."""
+import argparse
+import json
+import os
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+DEV = torch.device("cuda", 0)
+
+
+def make_trainer(out_dir, B, use_graph=True, group=None, n=96, **kw):
+    from ultrafnd_git_amd.trainer import ForensicTrainer, TrainConfig, synthetic_cache
+    cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir=out_dir, batch_size=B, device="cuda:0", use_graph=use_graph, **kw)
+    return ForensicTrainer(cfg, cache=synthetic_cache(n, seed=3), group=group)
+
+
+def dict_batches(B, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n):
+        out.append({"text_features": torch.randn(B, 768, generator=g).to(DEV), "audio_features": torch.randn(B, 128, generator=g).to(DEV),
+                    "visual_features": torch.randn(B, 512, generator=g).to(DEV), "temporal_features": torch.randn(B, 256, generator=g).to(DEV),
+                    "gnn_feat": torch.randn(B, 128, generator=g).to(DEV), "aux": torch.rand(B, 2, generator=g).to(DEV),
+                    "label": torch.randint(0, 2, (B,), generator=g).to(DEV)})
+    return out
+
+
+def force1(out_dir):
+    from ultrafnd_git_amd.dp import init_process_group
+    init_process_group(DEV)
+    res = {}
+    B = 16
+    arenas = {}
+    for tag, active in (("exchange", True), ("plain", False)):
+        for graph in (True, False):
+            torch.manual_seed(5)
+            tr = make_trainer(out_dir, B, use_graph=graph)
+            assert tr.reducer.force and tr.reducer.active and len(tr.reducer.buckets) == 2
+            if not active:
+                tr.reducer.force = False
+                assert not tr.reducer.active
+            tr.fusion.train(); tr.clf.train()
+            for b in dict_batches(B, 3, 11):
+                out = tr.train_step(b)
+            st = tr.optim.state.read()
+            arenas[(tag, graph)] = (tr.arena.data.clone(), out["logits"].clone(), float(st.grad_norm), int(st.step))
+    ref = arenas[("plain", False)]
+    res["plain_steps_bit_identical"] = all(torch.equal(v[0], ref[0]) and torch.equal(v[1], ref[1]) and v[2] == ref[2] for v in arenas.values())
+    res["steps"] = ref[3]
+    # pipelined steps (encoders inside the step, small encoders): exchange active vs none
+    from oracle import encoders_ref as E
+    from ultrafnd_git_amd.encoders import BertTextEncoder, ClipVisualEncoder
+    from ultrafnd_git_amd.trainer import ForensicTrainer, TrainConfig, synthetic_cache
+    wt = E.seeded_weights(E.bert_shapes(layers=2, vocab=500), 11)
+    wv = E.seeded_weights(E.vit_shapes(layers=2), 12)
+    pipe = {}
+    for tag, active in (("exchange", True), ("plain", False)):
+        torch.manual_seed(7)
+        tenc, venc = BertTextEncoder(layers=2, vocab_size=500), ClipVisualEncoder(layers=2)
+        tenc.load_state_dict(wt); venc.load_state_dict(wv)
+        tenc, venc = tenc.to(DEV), venc.to(DEV)
+        cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir=out_dir, batch_size=8, device="cuda:0", use_graph=True, encode_inline=True)
+        tr = ForensicTrainer(cfg, cache=synthetic_cache(32, seed=1), text_encoder=tenc, visual_encoder=venc)
+        if not active:
+            tr.reducer.force = False
+        tr.fusion.train(); tr.clf.train()
+        raws = []
+        for k in range(3):
+            ids, mask = E.synthetic_tokens(20 + k, 8, 32, vocab=500, min_len=8)
+            d = dict_batches(8, 1, 30 + k)[0]
+            d.update({"input_ids": ids.to(DEV), "attention_mask": mask.to(torch.int32).to(DEV), "frames": E.synthetic_frames(40 + k, 8, 1).to(DEV)})
+            raws.append(d)
+        tr.prefetch_features(raws[0])
+        for k in range(3):
+            out = tr.train_step_pipelined(raws[k], raws[k + 1] if k + 1 < 3 else None)
+        torch.cuda.synchronize()
+        pipe[tag] = (tr.arena.data.clone(), out["logits"].clone())
+    res["pipelined_bit_identical"] = bool(torch.equal(pipe["exchange"][0], pipe["plain"][0]) and torch.equal(pipe["exchange"][1], pipe["plain"][1]))
+    res["backend"] = dist.get_backend()
+    print(json.dumps(res))
+    dist.destroy_process_group()
+
+
+def world2(out_dir):
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    B = 8                                            # global batch; every rank takes B / world rows
+    batches = dict_batches(B, 3, 17)
+    ref = None
+    if rank == 0:                                    # single-process full-batch reference, BEFORE the group exists
+        torch.manual_seed(5)
+        tr0 = make_trainer(os.path.join(out_dir, "ref"), B, use_graph=False)
+        tr0.fusion.dropout = tr0.clf.dropout = tr0.clf.node_dropout = 0.0
+        tr0._step_bufs.clear()
+        tr0.fusion.train(); tr0.clf.train()
+        for b in batches:
+            o = tr0.train_step(b)
+        ref = (tr0.arena.data.clone(), float(tr0.optim.state.read().grad_norm))
+        del tr0
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(5)
+    tr = make_trainer(out_dir, B // world, use_graph=True)
+    assert tr.world == world and tr.reducer.active and abs(tr.reducer.grad_scale - 0.5) < 1e-12
+    tr.fusion.dropout = tr.clf.dropout = tr.clf.node_dropout = 0.0
+    tr._step_bufs.clear()
+    tr.fusion.train(); tr.clf.train()
+    for b in batches:
+        shard = {k: v[rank::world].contiguous() for k, v in b.items()}
+        tr.train_step(shard)
+    torch.cuda.synchronize()
+    res = {}
+    gn = float(tr.optim.state.read().grad_norm)
+    if rank == 0:
+        err = (tr.arena.data - ref[0]).abs().max().item()
+        scale = ref[0].abs().max().item()
+        res.update({"param_max_abs_err": err, "param_scale": scale, "grad_norm": gn, "grad_norm_ref": ref[1],
+                    "via_host": bool(tr.reducer._via_host)})
+    # every rank holds the same parameters after the exchange
+    mine = tr.arena.data.cpu()
+    other = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(other, mine)
+    res["ranks_agree"] = bool(all(torch.equal(o, other[0]) for o in other))
+    # fit / test with sharded loaders, gathered metrics, rank-0 checkpoint + broadcast
+    from ultrafnd_git_amd.trainer import ForensicTrainer, TrainConfig, synthetic_cache
+    cache = synthetic_cache(150, seed=9)
+    y = cache["labels"].astype(np.float32)
+    t = cache["text"].copy()
+    t[:, :64] += (2 * y[:, None] - 1) * 0.15
+    cache["text"] = t / np.linalg.norm(t, axis=1, keepdims=True)
+    cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir=os.path.join(out_dir, "fit"), batch_size=8, epochs=3, device="cuda:0",
+                      lr=1e-3, early_stop_patience=8)
+    tr2 = ForensicTrainer(cfg, cache=cache)
+    best = tr2.fit()
+    out = tr2.test()
+    vals = torch.tensor([best, out["test_auc"], out["test_loss"]], dtype=torch.float64)
+    allv = [torch.empty_like(vals) for _ in range(world)]
+    dist.all_gather(allv, vals)
+    res["fit_ranks_agree"] = bool(all(torch.equal(a, allv[0]) for a in allv))
+    res["best_val_auc"], res["test_auc"] = float(best), float(out["test_auc"])
+    res["ckpt_exists"] = os.path.exists(tr2.ckpt_path)
+    n_val = len(tr2.val_loader.dataset)
+    per_rank = torch.tensor([sum(dict.__getitem__(b, "index").numel() for b in tr2.val_loader)], dtype=torch.int64)
+    cnt = [torch.empty_like(per_rank) for _ in range(world)]
+    dist.all_gather(cnt, per_rank)
+    res["val_rows_total"], res["val_rows_split"] = int(sum(int(c) for c in cnt)), n_val
+    if rank == 0:
+        print(json.dumps(res))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", required=True)
+    ap.add_argument("--out", required=True)
+    a = ap.parse_args()
+    torch.cuda.set_device(0)
+    {"force1": force1, "world2": world2}[a.mode](a.out)

@@ -16,7 +16,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, tmp):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -37,10 +37,18 @@ def _worker(rank, world, port, q):
         arena.ensure_grad()
         for k in keys:
             arena.grad_view(k).copy_(grads[k])
+        local = arena.grad.clone()
         red = GradReducer(arena.grad)
-        assert red.world == world and abs(red.grad_scale - 1.0 / world) < 1e-12
+        assert red.world == world and abs(red.grad_scale - 1.0 / world) < 1e-12 and red.active
         red.start(); red.finish()
         mean = arena.grad * red.grad_scale
+        # the bucketed form the trainer uses (two buckets, started separately) reduces to the same bits
+        arena.grad.copy_(local)
+        cut = arena.offsets[keys[len(keys) // 2]][0]
+        red2 = GradReducer(arena.grad, bounds=[cut])
+        assert red2.buckets == [(0, cut), (cut, arena.grad.numel())]
+        red2.start(0); red2.start(1); red2.finish()
+        assert torch.equal(arena.grad * red2.grad_scale, mean)
         if rank == 0:
             _, _, gf0, gc0 = O.loss_and_grads(fus, clf, full)
             ref = {**{"fusion." + k: g for k, g in gf0.items()}, **{"clf." + k: g for k, g in gc0.items()}}
@@ -49,36 +57,87 @@ def _worker(rank, world, port, q):
                 o, shape = arena.offsets[k]
                 got = mean[o:o + ref[k].numel()].view(shape)
                 worst = max(worst, (got - ref[k]).abs().max().item() / max(1e-6, ref[k].abs().max().item()))
-            rows = gather_rows(torch.arange(4.0).view(4, 1) + 10 * rank)
-            q.put(("ok", worst, rows.flatten().tolist()))
-        else:
-            gather_rows(torch.arange(4.0).view(4, 1) + 10 * rank)
+        rows = gather_rows(torch.arange(4.0).view(4, 1) + 10 * rank)
+        extra = _epoch_level_checks(rank, world, tmp)
+        if rank == 0:
+            q.put(("ok", worst, rows.flatten().tolist(), extra))
     except Exception as e:  # pragma: no cover
         if rank == 0:
-            q.put(("err", repr(e), None))
+            q.put(("err", repr(e), None, None))
         raise
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_gradient_allreduce_equals_full_batch():
+def _epoch_level_checks(rank, world, tmp):
+    """The trainer's epoch-level data-parallel steps without a device: uneven evaluation shards gathered without
+    duplicates, the loss mean over all ranks' batches, the rank-0 atomic checkpoint + barrier, the broadcast of rank
+    0's parameters, and the loaders' sharding (DeviceBatchLoader over a host-resident CachedTensorDataset)."""
+    import os as _os
+
+    from ultrafnd_git_amd.dp import broadcast_from_rank0, gather_epoch_outputs, gather_rows, save_checkpoint
+    from ultrafnd_git_amd.trainer import CachedTensorDataset, DeviceBatchLoader, synthetic_cache
+    out = {}
+    # uneven rows per rank (validation shards are not padded)
+    mine = torch.arange(3 + rank, dtype=torch.float32).view(-1, 1) + 100 * rank
+    out["uneven"] = gather_rows(mine).flatten().tolist()
+    y = torch.arange(2 + rank)
+    p1 = torch.linspace(0, 1, 2 + rank)
+    f = torch.arange(3 * (2 + rank), dtype=torch.float32).view(3, -1)
+    ys, ps, fs, lm = gather_epoch_outputs(y, p1, f, torch.tensor(1.0 + rank), 1 + rank, None)
+    out["epoch"] = (ys.tolist(), tuple(fs.shape), float(lm))
+    # checkpoint: rank 0 writes, nobody reads a partial file
+    path = _os.path.join(tmp, "best.pt")
+    save_checkpoint({"w": torch.full((4,), 7.0)}, path, None)
+    assert _os.path.exists(path) and not [n for n in _os.listdir(tmp) if ".tmp." in n]
+    ck = torch.load(path, weights_only=True)
+    assert ck["w"].tolist() == [7.0] * 4
+    t = torch.full((5,), float(rank + 1))
+    broadcast_from_rank0(t, None)
+    out["bcast"] = t.tolist()
+    # loaders: the training shards are wrapped to equal length, the evaluation shards partition the split exactly
+    cache = synthetic_cache(40, seed=3)
+    ds = CachedTensorDataset(cache, cache["split"][1])         # 6 validation rows
+    ev = DeviceBatchLoader(ds, 4, shuffle=False)
+    tr = DeviceBatchLoader(CachedTensorDataset(cache, cache["split"][0]), 4, shuffle=True, seed=5)   # 28 training rows
+    got = torch.cat([dict.__getitem__(b, "index") for b in ev]) if len(ev) else torch.zeros(0, dtype=torch.int64)
+    out["eval_rows"] = gather_rows(got.view(-1, 1).float()).flatten().tolist()
+    out["eval_n"] = len(ds)
+    n_tr = sum(dict.__getitem__(b, "index").numel() for b in tr)
+    out["train_rows_per_rank"] = gather_rows(torch.tensor([[float(n_tr)]])).flatten().tolist()
+    b0 = next(iter(ev))
+    assert set(b0.keys()) >= {"text_features", "audio_features", "visual_features", "temporal_features", "aux", "label", "index"}
+    assert b0["text_features"].shape[1] == 768
+    return out
+
+
+def test_two_rank_gradient_allreduce_equals_full_batch(tmp_path):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
     for p in procs:
         p.start()
-    status, worst, rows = q.get(timeout=600)
+    status, worst, rows, extra = q.get(timeout=600)
     for p in procs:
         p.join(timeout=600)
         assert p.exitcode == 0
     assert status == "ok", worst
     assert worst <= 2e-5, worst          # mean of the two shard-mean gradients == full-batch mean gradient
     assert rows == [0.0, 1.0, 2.0, 3.0, 10.0, 11.0, 12.0, 13.0]
+    assert extra["uneven"] == [0.0, 1.0, 2.0, 100.0, 101.0, 102.0, 103.0]
+    ys, fshape, lm = extra["epoch"]
+    assert ys == [0, 1, 0, 1, 2] and fshape == (3, 5) and abs(lm - (1.0 + 2.0) / 3) < 1e-6      # loss sums / total batches
+    assert extra["bcast"] == [1.0] * 5
+    assert sorted(extra["eval_rows"]) == [float(i) for i in range(extra["eval_n"])]              # every row once, none twice
+    assert extra["train_rows_per_rank"] == [14.0, 14.0]
 
 
 def test_shard_indices_partition_and_padding():
     from ultrafnd_git_amd.dp import shard_indices
+    for n, world in ((10, 2), (11, 4), (3, 8)):          # pad=False: an exact partition, shards may differ by one
+        per = [shard_indices(n, world, r, pad=False) for r in range(world)]
+        assert sorted(torch.cat(per).tolist()) == list(range(n))
     for n, world in ((10, 2), (11, 4), (3, 8), (32, 8)):
         per = [shard_indices(n, world, r) for r in range(world)]
         assert len({p.numel() for p in per}) == 1 and per[0].numel() == -(-n // world)

@@ -1,0 +1,49 @@
+"""GPU: the data-parallel leg of the step on the one MI355X this box has.
+
+Each test runs a FRESH process tree under `python -m torch.distributed.run` (started by tests/launcher.py, a process
+that never touched the GPU): tests/dp_child.py does the work and prints one JSON line."""
+import json
+import socket
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(launch_job, nproc, mode, out_dir, env):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), "tests/dp_child.py", "--mode", mode, "--out", str(out_dir)]
+    r = launch_job(cmd, env={"HSA_ENABLE_IPC_MODE_LEGACY": "0", **env}, timeout=900)
+    assert r["rc"] == 0, (r["rc"], r["out"][-3000:], r["err"][-6000:])
+    line = [ln for ln in r["out"].splitlines() if ln.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_forced_rccl_exchange_on_one_rank_changes_no_bit(launch_job, tmp_path):
+    """torchrun world 1, RCCL, UFND_FORCE_REDUCE=1: init_process_group (high-priority group stream), the two-bucket
+    asynchronous all-reduce started inside backward (two captured head graphs with the collectives between them),
+    grad_scale in the norm / AdamW, graph capture with the process group alive -- three plain steps (graph and eager)
+    and three pipelined steps leave the arena bit-identical to the same steps without any exchange."""
+    res = _run(launch_job, 1, "force1", tmp_path, {"UFND_FORCE_REDUCE": "1"})
+    assert res["backend"] == "nccl" and res["steps"] == 3
+    assert res["plain_steps_bit_identical"] and res["pipelined_bit_identical"], res
+
+
+def test_two_ranks_on_one_gpu_equal_the_full_batch_step(launch_job, tmp_path):
+    """Two ranks sharing the GPU (gloo; gradients through pinned host memory): sharded batch + summed bucketed
+    gradients + 1/world folded into grad_scale == the single-process full-batch trainer, three steps; then fit() /
+    test() over sharded loaders: gathered metrics agree on both ranks, evaluation shards partition the split
+    (no wrapped duplicates), rank 0 checkpoints and every rank tests with rank 0's parameters."""
+    res = _run(launch_job, 2, "world2", tmp_path, {})
+    assert res["ranks_agree"] and res["fit_ranks_agree"] and res["ckpt_exists"], res
+    assert res["param_max_abs_err"] <= 2e-5 * max(1.0, res["param_scale"]), res
+    assert abs(res["grad_norm"] - res["grad_norm_ref"]) <= 1e-4 * max(1.0, res["grad_norm_ref"]), res
+    assert res["val_rows_total"] == res["val_rows_split"], res
+    assert 0.5 < res["best_val_auc"] <= 1.0

@@ -41,6 +41,7 @@ def where(stream, blocks=256, spin=1 << 22, graph=False):
     cu, sh, se = (hw >> 8) & 0xF, (hw >> 12) & 0x1, (hw >> 13) & 0x7
     keys = Counter((int(x), int(s), int(h), int(c)) for x, s, h, c in zip(xcc, se, sh, cu))
     per_xcc = Counter(k[0] for k in keys)
+    where.last_keys = set(keys)
     return {"distinct_cus": len(keys), "per_xcc": dict(sorted(per_xcc.items())), "max_blocks_on_one_cu": max(keys.values())}
 
 
@@ -74,12 +75,25 @@ def time_gemm(calls, reps=30):
 
 def main():
     res = {"cu_count": L.lib().ufnd_device_cu_count()}
+    if "--placement-only" in sys.argv:
+        for layout in ("striped", "block"):
+            bt, bv = partition_bits((192, 64), layout)
+            st, sv = MaskedStream(dev, bt), MaskedStream(dev, bv)
+            a = where(sv, 128); kv = where.last_keys
+            b = where(st, 256)
+            res[layout] = {"vis": a["distinct_cus"], "text": b["distinct_cus"], "shared": len(kv & where.last_keys)}
+        print(json.dumps(res))
+        return
     plain = torch.cuda.Stream(device=dev)
     res["unmasked"] = where(plain, 256)
     for layout in ("striped", "block"):
         bt, bv = partition_bits((192, 64), layout)
         st, sv = MaskedStream(dev, bt), MaskedStream(dev, bv)
-        res[layout] = {"vis64_eager": where(sv, 128), "vis64_graph": where(sv, 128, graph=True), "text192_eager": where(st, 256)}
+        res[layout] = {"vis64_eager": where(sv, 128)}
+        kv = where.last_keys
+        res[layout]["vis64_graph"] = where(sv, 128, graph=True)
+        res[layout]["text192_eager"] = where(st, 256)
+        res[layout]["cus_shared_by_text_and_vis"] = len(kv & where.last_keys)
         # timing
         q_text, q_vis = (4096, 2304, 768, 22), (1600, 2304, 768, 15)
         res[layout]["us"] = {

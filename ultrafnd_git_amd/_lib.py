@@ -77,6 +77,7 @@ class GemmLn(C.Structure):
 
 
 STEP_STATE_BYTES = C.sizeof(StepState)
+BWD_ALL, BWD_FUSE_MLP, BWD_REST = 0, 1, 2
 ABI_VERSION = 2
 
 _lib: Optional[C.CDLL] = None
@@ -95,6 +96,9 @@ def _declare(lib: C.CDLL) -> None:
     lib.ufnd_fusion_forward.argtypes = [C.POINTER(Dims), C.POINTER(FusionParams), P, P, P, P, P, I, I, P, P, I, P, P, P, P]
     lib.ufnd_fusion_backward.argtypes = [C.POINTER(Dims), C.POINTER(FusionParams), C.POINTER(FusionParams),
                                          P, P, P, P, P, I, I, P, P, I, P, P, P, P, I]
+    lib.ufnd_fusion_backward_phase.argtypes = [C.POINTER(Dims), C.POINTER(FusionParams), C.POINTER(FusionParams),
+                                               P, P, P, P, P, I, I, P, P, I, P, P, P, P, I, I]
+    lib.ufnd_fusion_backward_phase.restype = I
     lib.ufnd_classifier_forward.argtypes = [C.POINTER(Dims), C.POINTER(ClfParams), P, I, P, I, I, P, P, P, P, P]
     lib.ufnd_classifier_backward.argtypes = [C.POINTER(Dims), C.POINTER(ClfParams), C.POINTER(ClfParams), I, I, P, P, P,
                                              I, P, P, P, I]

@@ -815,14 +815,16 @@ extern "C" int ufnd_fusion_forward(const ufnd_dims* d, const ufnd_fusion_params*
   return UFND_OK;
 }
 
-extern "C" int ufnd_fusion_backward(const ufnd_dims* d, const ufnd_fusion_params* p, const ufnd_fusion_params* g,
-                                    const float* text, const float* audio, const float* visual, const float* temporal,
-                                    const float* gnn, int B, int train, float* workspace, const float* d_fused,
-                                    int ld_dfused, const float* d_logits, const ufnd_step_state* state, void* stream_, void* side_stream_,
-                                    int join) {
+extern "C" int ufnd_fusion_backward_phase(const ufnd_dims* d, const ufnd_fusion_params* p, const ufnd_fusion_params* g,
+                                          const float* text, const float* audio, const float* visual, const float* temporal,
+                                          const float* gnn, int B, int train, float* workspace, const float* d_fused,
+                                          int ld_dfused, const float* d_logits, const ufnd_step_state* state, void* stream_,
+                                          void* side_stream_, int join, int phase) {
   TRY(check_dims(d, B));
+  UFND_REQUIRE(phase == UFND_BWD_ALL || phase == UFND_BWD_FUSE_MLP || phase == UFND_BWD_REST, "fusion_backward: phase=%d", phase);
+  const bool do_head = phase != UFND_BWD_REST, do_rest = phase != UFND_BWD_FUSE_MLP;
   UFND_REQUIRE(p && g && text && audio && visual && temporal && gnn && workspace && state, "fusion_backward: null argument");
-  UFND_REQUIRE(d_fused || d_logits, "fusion_backward: no incoming gradient");
+  UFND_REQUIRE(!do_head || d_fused || d_logits, "fusion_backward: no incoming gradient");
   hipStream_t stream = (hipStream_t)stream_;
   const ForkJoin fj{stream, (hipStream_t)side_stream_};
   const int H = d->hidden;
@@ -835,6 +837,7 @@ extern "C" int ufnd_fusion_backward(const ufnd_dims* d, const ufnd_fusion_params
   TnProb tn[UFND_GEMM_MAX_PROB];
   int ntn = 0;
 
+  if (do_head) {
   // aux-head parameter grads (only when a gradient arrives at the aux logits)
   if (d_logits) {
     hipLaunchKernelGGL(head2_bwd_kernel, dim3(ufnd_cdiv(H, 256)), blk, 0, stream, d_logits, (const float*)w.z2, B, H,
@@ -856,8 +859,18 @@ extern "C" int ufnd_fusion_backward(const ufnd_dims* d, const ufnd_fusion_params
     tn[ntn++] = TnProb{w.dz1, w.cat, g->fuse0_w, g->fuse0_b, B, 2 * H, 16 * H, 2 * H, 16 * H, 16 * H};
     NnProb n{w.dz1, p->fuse0_w, w.dcatp, nullptr, nullptr, B, 2 * H, 16 * H, 2 * H, 16 * H, 16 * H, 0, 0, 0.0f, 0, 0,
              NSPLIT_FUSE0};
+    if (phase == UFND_BWD_FUSE_MLP) {
+      // bucketed gradient exchange: the two fuse_mlp weight gradients (67 % of all gradient bytes) are written NOW,
+      // ahead of the dCAT product, so that the caller can start reducing them while the rest of backward runs
+      // (the grouped launch computes every problem independently: the same bits as the one-launch form)
+      fj.fork(1);
+      TRY(launch_tn(tn, ntn, fj.dw()));
+      ntn = 0;
+    }
     TRY(launch_nn(&n, 1, state, stream));
   }
+  }  // do_head
+  if (do_rest) {
   // concat / pairwise / co-attention backward (row-wise)
   const dim3 slices(ufnd_cdiv(B * (H / 256), 4));       // one wave per 256-column slice of a row
   NI_DISPATCH(H, coattn_pairs_bwd_kernel, slices, blk, stream, (const float*)w.dcatp, NSPLIT_FUSE0, (const float*)w.cat,
@@ -900,8 +913,18 @@ extern "C" int ufnd_fusion_backward(const ufnd_dims* d, const ufnd_fusion_params
     for (int i = 0; i < 5; ++i) tn[ntn++] = TnProb{dys[i], xs[i], gw[i], gb[i], B, H, ks[i], H, ks[i], ks[i]};
     TRY(launch_tn(tn, ntn, fj.dw()));
   }
+  }  // do_rest
   if (join) fj.join(4);
   return UFND_OK;
+}
+
+extern "C" int ufnd_fusion_backward(const ufnd_dims* d, const ufnd_fusion_params* p, const ufnd_fusion_params* g,
+                                    const float* text, const float* audio, const float* visual, const float* temporal,
+                                    const float* gnn, int B, int train, float* workspace, const float* d_fused,
+                                    int ld_dfused, const float* d_logits, const ufnd_step_state* state, void* stream_, void* side_stream_,
+                                    int join) {
+  return ufnd_fusion_backward_phase(d, p, g, text, audio, visual, temporal, gnn, B, train, workspace, d_fused, ld_dfused, d_logits,
+                                    state, stream_, side_stream_, join, UFND_BWD_ALL);
 }
 
 extern "C" int ufnd_classifier_forward(const ufnd_dims* d, const ufnd_clf_params* p, const float* fused, int ld_fused,

@@ -52,7 +52,7 @@ def mask_words(bits: Sequence[int], n_words: int = 8):
 
 
 class MaskedStream(torch.cuda.ExternalStream):
-    """torch view of a hipStream_t created by ufnd_stream_create_cu_mask; owns and destroys it."""
+    """torch view of a hipStream_t created by ufnd_stream_create_cu_mask (close() destroys it)."""
 
     def __new__(cls, device: torch.device, bits: Sequence[int]):
         words = mask_words(bits)
@@ -63,10 +63,10 @@ class MaskedStream(torch.cuda.ExternalStream):
         self._raw, self.cu_bits = out.value, tuple(bits)
         return self
 
-    def __del__(self):
+    def close(self) -> None:
+        """Destroy the stream (it must be idle and no captured graph may still name it).  Streams that are never
+        closed live as long as the process: tearing a stream down from a finalizer at interpreter exit, after the
+        allocator and graphs that reference it, faults inside the HIP runtime."""
         raw, self._raw = getattr(self, "_raw", None), None
         if raw:
-            try:
-                L.lib().ufnd_stream_destroy(raw)
-            except Exception:
-                pass
+            L.check(L.lib().ufnd_stream_destroy(raw), "ufnd_stream_destroy")

@@ -18,8 +18,9 @@ What is different, on purpose (SURVEY.md 3 "hot loops today", 8e):
   * optional `encode_inline`: raw token ids / frames go through the native BERT / ViT encoders
     inside the step (the north-star's "text+vision" step) instead of precomputed features.
 Out of scope: FakeSVRawDataset / build_gnn_cache_from_raw_dataset (dataset
-preprocessing needing the FakeSV corpus) and SimpleGCN (init-time only, output detached): the
-trainer takes the cache dict they would have produced, `gnn_Z` included.
+preprocessing needing the FakeSV corpus): the trainer takes the cache dict they would have produced.  When that
+cache carries `ocr_sets` instead of `gnn_Z`, the graph side of the reference's construction (OCR-Jaccard
+adjacency, SimpleGCN, its two pre-training steps; forensic_trainer.py:184-224) runs here too (gcn.py).
 """
 from __future__ import annotations
 
@@ -34,7 +35,7 @@ import torch
 from . import _lib as L
 from .arena import rehome
 from .classifier import DeepTruthClassifier
-from .dp import GradReducer, gather_rows, shard_indices, world_info
+from .dp import GradReducer, broadcast_from_rank0, gather_epoch_outputs, save_checkpoint, shard_indices, world_info
 from .fusion import CrossModalTransformer
 from .metrics import aggregate_epoch_metrics, pretty_print
 from .optim import CosineAnnealingLR, FusedAdamW, StepLR
@@ -173,8 +174,11 @@ class DeviceBatchLoader:
     """DataLoader(dataset, batch_size, shuffle, drop_last=False) over a device-resident split,
     sharded across data-parallel ranks (DistributedSampler semantics)."""
 
-    def __init__(self, dataset: CachedTensorDataset, batch_size: int, shuffle: bool, seed: int = 0, group=None):
+    def __init__(self, dataset: CachedTensorDataset, batch_size: int, shuffle: bool, seed: int = 0, group=None, pad: Optional[bool] = None):
         self.dataset, self.batch_size, self.shuffle, self.seed, self.group = dataset, int(batch_size), shuffle, seed, group
+        # training shards are wrapped to equal length (every rank takes the same number of steps: one collective per
+        # step); evaluation shards are not, so that no sample enters the epoch metrics twice
+        self.pad = shuffle if pad is None else pad
         self.epoch = 0
 
     def _indices(self) -> torch.Tensor:
@@ -184,7 +188,7 @@ class DeviceBatchLoader:
         if self.shuffle:
             g = torch.Generator().manual_seed(self.seed + self.epoch)
             perm = torch.randperm(n, generator=g)
-        return shard_indices(n, world, rank, perm)
+        return shard_indices(n, world, rank, perm, pad=self.pad)
 
     def __len__(self):
         n = self._indices().numel()
@@ -243,7 +247,8 @@ class ForensicTrainer:
         self.clf = DeepTruthClassifier(config_path="configs/model_configs/classifier.yaml").to(self.device)
         # one flat arena for both modules: clf first (its gradients are ready first in backward)
         self.arena = rehome([self.clf, self.fusion], ["clf.", "fusion."])
-        self.reducer = GradReducer(self.arena.ensure_grad(), group=group)
+        # two buckets in gradient-ready order: [classifier | fuse_mlp] is complete after the first phase of backward
+        self.reducer = GradReducer(self.arena.ensure_grad(), group=group, bounds=[self.arena.offsets["fusion.attn_tv.q.weight"][0]])
         self.optim = FusedAdamW(self.arena, lr=cfg.lr, weight_decay=cfg.weight_decay,
                                 max_norm=cfg.grad_clip if cfg.grad_clip and cfg.grad_clip > 0 else 0.0,
                                 seed=cfg.seed + 1000 * self.rank, grad_scale=self.reducer.grad_scale)
@@ -374,7 +379,9 @@ class ForensicTrainer:
             L.check(lib.ufnd_softmax_ce(b["logits"].data_ptr(), b["label"].data_ptr(), B, None,
                                         b["dlogits"].data_ptr() if with_loss_grad else None, st, s), "ufnd_softmax_ce")
 
-    def _enqueue_backward(self, b: dict, B: int) -> None:
+    def _enqueue_backward(self, b: dict, B: int, part: int = 0) -> None:
+        """part 0: the whole backward; 1: classifier backward + the fuse_mlp phase of the fusion backward (bucket 0 of
+        the gradient exchange is complete afterwards); 2: the rest of the fusion backward."""
         lib, s, st = L.lib(), L.stream_ptr(self.device), self.optim.state.ptr
         d = b["dims"]
         # Eager launches: dW / parameter-gradient kernels run beside the dX chain on a second stream (joined
@@ -385,33 +392,56 @@ class ForensicTrainer:
             if self._dw_stream is None:
                 self._dw_stream = torch.cuda.Stream(device=self.device)
             side = self._dw_stream.cuda_stream
-        L.check(lib.ufnd_classifier_backward(C.byref(d), C.byref(self.clf.param_table()), C.byref(self.clf.grad_table()), B, 1,
-                                             b["cws"].data_ptr(), b["dlogits"].data_ptr(), b["dfused"].data_ptr(),
-                                             self.fusion.hidden, st, s, side, 0), "ufnd_classifier_backward")
-        L.check(lib.ufnd_fusion_backward(C.byref(d), C.byref(self.fusion.param_table()), C.byref(self.fusion.grad_table()),
-                                         b["text"].data_ptr(), b["audio"].data_ptr(), b["visual"].data_ptr(),
-                                         b["temporal"].data_ptr(), b["gnn"].data_ptr(), B, 1, b["fws"].data_ptr(),
-                                         b["dfused"].data_ptr(), self.fusion.hidden, None, st, s, side, 1), "ufnd_fusion_backward")
+        if part != 2:
+            L.check(lib.ufnd_classifier_backward(C.byref(d), C.byref(self.clf.param_table()), C.byref(self.clf.grad_table()), B, 1,
+                                                 b["cws"].data_ptr(), b["dlogits"].data_ptr(), b["dfused"].data_ptr(),
+                                                 self.fusion.hidden, st, s, side, 0), "ufnd_classifier_backward")
+        L.check(lib.ufnd_fusion_backward_phase(C.byref(d), C.byref(self.fusion.param_table()), C.byref(self.fusion.grad_table()),
+                                               b["text"].data_ptr(), b["audio"].data_ptr(), b["visual"].data_ptr(),
+                                               b["temporal"].data_ptr(), b["gnn"].data_ptr(), B, 1, b["fws"].data_ptr(),
+                                               b["dfused"].data_ptr(), self.fusion.hidden, None, st, s, side, 1,
+                                               (L.BWD_ALL, L.BWD_FUSE_MLP, L.BWD_REST)[part]), "ufnd_fusion_backward_phase")
 
     def _fwd_bwd(self, b: dict, B: int) -> None:
-        """fusion fwd -> clf fwd -> CE -> clf bwd -> fusion bwd, eager or replayed from a hipGraph."""
-        if not self._head_graph:
+        """fusion fwd -> clf fwd -> CE -> clf bwd -> fusion bwd, eager or replayed from a hipGraph.  With a gradient
+        exchange (data parallel) the backward is cut after the fuse_mlp phase: bucket 0 of the exchange starts there and
+        runs beside the rest of backward, bucket 1 follows it (dp.py); the caller's reducer.finish() joins both."""
+        dp = self.reducer.active
+
+        def first():
             self._enqueue_forward(b, B, True, True)
-            self._enqueue_backward(b, B)
+            self._enqueue_backward(b, B, 1 if dp else 0)
+
+        def second():
+            self._enqueue_backward(b, B, 2)
+        if not self._head_graph:
+            first()
+            if dp:
+                self.reducer.start(0)
+                second()
+                self.reducer.start(1)
             return
-        if b["graph"] is None:
+        key = "graph_dp" if dp else "graph"
+        if b.get(key) is None:
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):          # warm-up outside capture (lazy module loads etc.)
-                self._enqueue_forward(b, B, True, True)
-                self._enqueue_backward(b, B)
+                first()
+                if dp:
+                    second()
             torch.cuda.current_stream(self.device).wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                self._enqueue_forward(b, B, True, True)
-                self._enqueue_backward(b, B)
-            b["graph"] = g
-        b["graph"].replay()
+            graphs = []
+            for fn in ((first, second) if dp else (first,)):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    fn()
+                graphs.append(g)
+            b[key] = graphs
+        b[key][0].replay()
+        if dp:
+            self.reducer.start(0)
+            b[key][1].replay()
+            self.reducer.start(1)
 
     def train_step(self, batch: Dict[str, torch.Tensor], split: str = "train") -> dict:
         """One iteration of the reference's train loop body (forensic_trainer.py:285-298):
@@ -420,7 +450,6 @@ class ForensicTrainer:
         b = self._bufs(B, True)
         self._load_batch(b, batch, split)
         self._fwd_bwd(b, B)
-        self.reducer.start()
         self.reducer.finish()
         self.optim.clip_and_step()
         return {"loss": self.optim.state.float_view("loss"), "probs": b["probs"], "y": b["label"],
@@ -563,17 +592,20 @@ class ForensicTrainer:
             b["temporal"].copy_(self.temporal_net.align_batch(b["text"], b["visual"]))
         else:
             b["temporal"].copy_(batch["temporal_features"])
+        # With a gradient exchange, the next batch's encoders are enqueued BEFORE the head: the RCCL launches inside
+        # _fwd_bwd hold the host until the work they depend on has run (measured: encoders enqueued after a collective
+        # reached the GPU 40 us after the head's end and the step degenerated into head -> encoders -> optimizer in
+        # series).  They read the other input slot, so the order of enqueueing changes no value.
+        early = next_batch is not None and self.reducer.active
+        if early:
+            self.prefetch_features(next_batch, slot ^ 1, inputs_ready)
         self._fwd_bwd(b, B)
         done = torch.cuda.Event()
         done.record(main)
         self._slot_free[slot] = done
         self._mark("head1", main)
-        # the next batch's encoders are enqueued BEFORE the collective: the RCCL launch holds the host until the
-        # head it depends on has finished (measured: the text graph otherwise reached the GPU 40 us after the
-        # head's end and the step degenerated into head -> encoders -> optimizer in series)
-        if next_batch is not None:
+        if next_batch is not None and not early:
             self.prefetch_features(next_batch, slot ^ 1, inputs_ready)
-        self.reducer.start()
         self.reducer.finish()
         self._mark("reduce1", main)
         self.optim.clip_and_step()
@@ -667,17 +699,17 @@ class ForensicTrainer:
             ys.append(out["y"].clone())
             p1s.append(out["probs"][:, 1].clone())
             fors.append(f.clone())
-        if not losses:
+        if not losses and self.world == 1:
             return 0.0, aggregate_epoch_metrics(np.array([], dtype=int), np.array([], dtype=float))
-        loss_mean_local = torch.stack(losses).mean()
-        y_cat, p1_cat, f_cat = torch.cat(ys), torch.cat(p1s), torch.cat(fors, dim=1)
-        if self.world > 1:   # metrics need every rank's rows (AUC is not decomposable)
-            y_cat = gather_rows(y_cat, self.group)
-            p1_cat = gather_rows(p1_cat, self.group)
-            f_cat = gather_rows(f_cat.t().contiguous(), self.group).t()
-            lm = loss_mean_local.clone()
-            torch.distributed.all_reduce(lm, group=self.group)
-            loss_mean_local = lm / self.world
+        if not losses:      # an empty evaluation shard still takes part in the gather
+            dev = self.device
+            losses, ys = [torch.zeros((), device=dev)], [torch.zeros(0, dtype=torch.int64, device=dev)]
+            p1s, fors = [torch.zeros(0, device=dev)], [torch.zeros(3, 0, device=dev)]
+            n_loss = 0
+        else:
+            n_loss = len(losses)
+        y_cat, p1_cat, f_cat, loss_mean_local = gather_epoch_outputs(torch.cat(ys), torch.cat(p1s), torch.cat(fors, dim=1),
+                                                                      torch.stack(losses).sum(), n_loss, self.group)
         loss_mean = float(loss_mean_local.cpu())
         f_np = f_cat.cpu().numpy()
         forensic = {"emotion_intensity": f_np[0], "semantic_conflict": f_np[1], "temporal_delay": f_np[2]}
@@ -702,10 +734,12 @@ class ForensicTrainer:
             if improved and self.cfg.save_best:
                 self.best_val_auc = val_auc
                 self.no_improve = 0
+                # rank 0 writes the file atomically; every rank leaves save_checkpoint only when it is complete
+                save_checkpoint({"fusion": {k: v.cpu() for k, v in self.fusion.state_dict().items()},
+                                 "clf": {k: v.cpu() for k, v in self.clf.state_dict().items()},
+                                 "gnn": self.gnn.state_dict() if self.gnn is not None else None, "cfg": dict(self.cfg.__dict__)},
+                                self.ckpt_path, self.group)
                 if self.rank == 0:
-                    torch.save({"fusion": {k: v.cpu() for k, v in self.fusion.state_dict().items()},
-                                "clf": {k: v.cpu() for k, v in self.clf.state_dict().items()},
-                                "gnn": self.gnn.state_dict() if self.gnn is not None else None, "cfg": dict(self.cfg.__dict__)}, self.ckpt_path)
                     print(f"  ↳ saved best checkpoint to {self.ckpt_path} (val_auc={self.best_val_auc:.3f})")
             else:
                 self.no_improve += 1
@@ -716,10 +750,13 @@ class ForensicTrainer:
         return self.best_val_auc
 
     def test(self) -> Dict[str, float]:
-        if os.path.exists(self.ckpt_path):
+        # rank 0 reads the checkpoint; every rank then continues with rank 0's parameters (one broadcast of the arena),
+        # so no rank ever evaluates its shard with a stale or half-written file
+        if self.rank == 0 and os.path.exists(self.ckpt_path):
             ck = torch.load(self.ckpt_path, map_location="cpu", weights_only=True)
             self.fusion.load_state_dict(ck["fusion"])
             self.clf.load_state_dict(ck["clf"])
+        broadcast_from_rank0(self.arena.data, self.group)
         self.fusion.eval()
         self.clf.eval()
         ts_loss, ts_metrics = self._epoch_loop(self.test_loader, "test")
