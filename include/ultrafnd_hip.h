@@ -249,6 +249,11 @@ int ufnd_gemm_bf16_ex(const void* A, const void* W, const float* bias, const flo
  * over `width` elements; partial layout and summation order are canonical (independent of the tile the
  * shape selects, no atomics): results are run-to-run identical and a row's outputs do not depend on the
  * batch it is computed in.
+ * Accuracy of the folded form.  The consumer multiplies the bf16 rounding of the UN-normalised row, so a common-mode
+ * offset of the row is rounded before it is subtracted: relative to the normalised output the error is about
+ * (1 + |mean| / std) * 2^-9 (measured: tests/test_gpu_tier_b.py::test_gemm_ln_fold_error_grows_with_the_row_offset).
+ * Rows of trained BERT / CLIP streams have |mean| / std well below 1; fold_guard publishes the largest ratio seen so
+ * that a caller can fall back to a materialised LayerNorm (ufnd_layernorm + ufnd_gemm_bf16) when it is not.
  * Replaces nn.LayerNorm + nn.Linear pairs of the third-party encoders (transformers modeling_bert.py
  * BertSelfOutput / BertOutput, modeling_clip.py CLIPEncoderLayer) behind text_blocks.py:79. */
 typedef struct ufnd_gemm_ln {
@@ -262,6 +267,7 @@ typedef struct ufnd_gemm_ln {
   float a_eps, r_eps;
   int width;
   int tile_cfg; /* < 0: automatic; otherwise a LayerNorm-aware tile id (ufnd_gemm_bf16_tile_info) */
+  float* fold_guard; /* optional (a_stats calls): *fold_guard = max(*fold_guard, |mean| * rstd of every row), see below */
 } ufnd_gemm_ln;
 int ufnd_gemm_bf16_ln(const void* A, const void* W, const float* bias, const float* residual, void* out_bf16,
                       float* out_f32, int M, int N, int K, int lda, int ldw, int ldr, int ldo, int ldf, int act,

@@ -50,3 +50,23 @@ def test_product_never_imports_the_oracle():
     for f in (REPO / "ultrafnd_git_amd").rglob("*.py"):
         src = f.read_text()
         assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_diagnostics_are_not_reachable_through_the_product_library():
+    """Timing ablations, in-kernel stamps and experimental tiles live in libultrafnd_hip_diag.so (csrc/diag/): the
+    product library exports none of them, has no environment override of the tile choice, and the package never
+    loads the diagnostics library."""
+    import torch  # noqa: F401
+    from ultrafnd_git_amd.build import build
+    lib = ctypes.CDLL(str(build()))
+    for name in ("ufnd_gemm_bf16_stamps", "ufnd_diag_gemm_bf16_stamps", "ufnd_diag_gemm_bf16_ex", "ufnd_diag_where"):
+        assert not hasattr(lib, name), name
+    blob = Path(build()).read_bytes()
+    assert b"UFND_GEMM_FORCE_CFG" not in blob
+    for f in (REPO / "ultrafnd_git_amd").rglob("*.py"):
+        if f.name != "build.py":
+            assert "hip_diag" not in f.read_text(), f
+    # the tile table query is host-only: ids built into the library answer 1, others 0
+    n = lib.ufnd_gemm_bf16_tile_count()
+    built = [t for t in range(n) if lib.ufnd_gemm_bf16_tile_info(t, None, None, None)]
+    assert 4 <= len(built) < n and lib.ufnd_gemm_bf16_tile_info(n, None, None, None) == 0 and lib.ufnd_gemm_bf16_tile_info(-1, None, None, None) == 0

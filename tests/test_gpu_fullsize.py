@@ -1,0 +1,194 @@
+"""GPU parity at the sizes BASELINE.json names, and the accuracy range of the folded LayerNorm.
+
+The CPU oracle cannot run 65,536 tokens through 12 layers in test time, but rows of a batch are independent through
+both encoders (attention stays inside a sample; the batch-invariance test holds that bit for bit), so a few SAMPLED
+rows of the full-size GPU batch are checked against the oracle run on those rows alone.
+
+Tolerances (bf16 operands, fp32 accumulation / residual stream / statistics): a GEMM output carries the 2^-9 relative
+rounding of its two operands; a post-LN hidden state (entries of order 1) after 12 layers x 4 Linears sits at
+2^-9 * sqrt(48) ~ 1.4e-2 relative RMS, features (unit vectors pooled over up to 512 tokens) at <= 6e-3 max-abs, and the
+head maps that to <= 1e-3 on the logits (north_star's bound).
+"""
+import ctypes as C
+import warnings
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_bert_base_L512_B128_vocab30522_sampled_rows_vs_oracle():
+    """BASELINE configs[3]: text-only geometry at full depth, length, batch and vocabulary."""
+    from oracle import encoders_ref as E
+    from ultrafnd_git_amd.encoders import BertTextEncoder
+    B, Lq = 128, 512
+    w = E.seeded_weights(E.bert_shapes(), 51)                       # 12 layers, vocab 30522, max_pos 512
+    enc = BertTextEncoder()
+    enc.load_state_dict(w)
+    enc = enc.to(DEV)
+    ids, mask = E.synthetic_tokens(151, B, Lq)
+    mask[5] = 1                                                     # one full-length row: four online-softmax key blocks, no padding
+    hid = enc.last_hidden_state(ids, mask).clone()
+    feat = enc(ids, mask).clone()
+    rows = [0, 5, 77, 127]
+    ref_h = E.bert_last_hidden_state(w, ids[rows], mask[rows])
+    ref_f = E.text_features(w, ids[rows], mask[rows])
+    ef = (feat[rows].cpu() - ref_f).abs().max().item()
+    worst_rel, worst_abs = 0.0, 0.0
+    for i, r in enumerate(rows):
+        n = int(mask[r].sum())
+        d = hid[r, :n].cpu() - ref_h[i, :n]
+        worst_rel = max(worst_rel, (d.pow(2).mean().sqrt() / ref_h[i, :n].pow(2).mean().sqrt()).item())
+        worst_abs = max(worst_abs, d.abs().max().item())
+    print(f"BERT-base L=512 B=128 vocab 30522: features max-abs-err {ef:.3e}; hidden rel-RMS {worst_rel:.3e} max-abs {worst_abs:.3e} "
+          f"(fold ratio {enc.fold_ratio():.2f})")
+    assert torch.isfinite(feat).all()
+    assert ef <= 6e-3, ef
+    assert worst_rel <= 1.5e-2 and worst_abs <= 0.12, (worst_rel, worst_abs)
+
+
+def test_vit_b32_8_frames_full_depth_vs_oracle():
+    """BASELINE configs[4] per-GPU shard geometry: 8 frames per sample through the 12-layer ViT-B/32."""
+    from oracle import encoders_ref as E
+    from ultrafnd_git_amd.encoders import ClipVisualEncoder
+    B, Fr = 8, 8
+    w = E.seeded_weights(E.vit_shapes(), 52)
+    enc = ClipVisualEncoder()
+    enc.load_state_dict(w)
+    enc = enc.to(DEV)
+    frames = E.synthetic_frames(152, B, Fr)
+    feat = enc(frames).clone()
+    rows = [0, 7]
+    ref = E.visual_features(w, frames[rows])
+    ef = (feat[rows].cpu() - ref).abs().max().item()
+    print(f"ViT-B/32 12 layers, 8 frames, B=8: features max-abs-err {ef:.3e} (fold ratio {enc.fold_ratio():.2f})")
+    assert ef <= 6e-3, ef
+
+
+def test_end_to_end_logits_full_geometry_B32():
+    """BASELINE configs[1] at its own size: B=32, L=128, vocab 30522, one 224^2 frame, 12-layer encoders -> fp32 head;
+    logits of 4 sampled rows within 1e-3 of the all-fp32 CPU path (head rows are independent in eval mode)."""
+    from oracle import encoders_ref as E
+    from oracle import tier_a as O
+    from ultrafnd_git_amd.classifier import DeepTruthClassifier
+    from ultrafnd_git_amd.encoders import BertTextEncoder, ClipVisualEncoder
+    from ultrafnd_git_amd.fusion import CrossModalTransformer
+    B, Lq = 32, 128
+    wt = E.seeded_weights(E.bert_shapes(), 61)
+    wv = E.seeded_weights(E.vit_shapes(), 62)
+    ids, mask = E.synthetic_tokens(161, B, Lq)
+    frames = E.synthetic_frames(162, B, 1)
+    batch = O.seeded_batch(163, B)
+    fus_sd, clf_sd = O.seeded_params(1234)
+    tenc, venc = BertTextEncoder(), ClipVisualEncoder()
+    tenc.load_state_dict(wt); venc.load_state_dict(wv)
+    tenc, venc = tenc.to(DEV), venc.to(DEV)
+    fusion, clf = CrossModalTransformer(), DeepTruthClassifier()
+    fusion.load_state_dict(fus_sd); clf.load_state_dict(clf_sd)
+    fusion, clf = fusion.to(DEV).eval(), clf.to(DEV).eval()
+    feats = {k: batch[k].to(DEV) for k in ("audio_features", "temporal_features", "gnn_feat")}
+    feats["text_features"] = tenc(ids, mask)
+    feats["visual_features"] = venc(frames)
+    with torch.no_grad():
+        fo = fusion(feats)
+        co = clf(fo["fused"], batch["aux"].to(DEV))
+    rows = [0, 9, 20, 31]
+    ref_b = {k: v[rows] for k, v in batch.items()}
+    ref_b["text_features"] = E.text_features(wt, ids[rows], mask[rows])
+    ref_b["visual_features"] = E.visual_features(wv, frames[rows])
+    ref = O.forward_batch(fus_sd, clf_sd, ref_b)
+    err = (co["logits"][rows].cpu() - ref["logits"]).abs().max().item()
+    ft = (feats["text_features"][rows].cpu() - ref_b["text_features"]).abs().max().item()
+    fv = (feats["visual_features"][rows].cpu() - ref_b["visual_features"]).abs().max().item()
+    print(f"end-to-end B=32 full geometry: logits max-abs-err {err:.3e} (text feat {ft:.2e}, visual feat {fv:.2e}); |logits| max {ref['logits'].abs().max().item():.3f}")
+    assert err <= 1e-3, err
+
+
+# ------------------------------------------------------------------------------------------ folded LayerNorm: accuracy range
+def _fold_case(M, N, K, ratio, seed):
+    """x rows with |mean| / std ~ ratio, three outlier columns, gamma / beta with a 10x spread."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(M, K, generator=g) + float(ratio) * torch.sign(torch.randn(M, 1, generator=g))
+    x[:, [3, 300, 511]] += 20.0 * torch.randn(M, 3, generator=g).sign()
+    gm = 10.0 ** (torch.rand(K, generator=g) - 0.5)                   # 0.32 .. 3.2
+    bt = torch.randn(K, generator=g) * gm
+    Wf = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    return x.to(DEV), gm.to(DEV), bt.to(DEV), Wf.to(DEV), b.to(DEV)
+
+
+def _run_fold(x, gm, bt, Wf, b, act=0):
+    from ultrafnd_git_amd import _lib as L
+    M, K = x.shape
+    N = Wf.shape[0]
+    Wp = (Wf * gm[None, :]).bfloat16()
+    colsum = Wp.float().sum(1).contiguous()
+    bias = (b + Wf @ bt).contiguous()
+    xs = x.view(M, 12, K // 12)
+    st = torch.stack([xs.sum(-1), (xs * xs).sum(-1)], -1).contiguous()
+    of = torch.empty(M, N, device=DEV)
+    guard = torch.zeros(1, device=DEV)
+    ln = L.GemmLn()
+    ln.a_stats, ln.colsum, ln.a_parts, ln.a_eps, ln.r_eps, ln.width = st.data_ptr(), colsum.data_ptr(), 12, 1e-5, 1e-5, K
+    ln.fold_guard = guard.data_ptr()
+    xb = x.bfloat16()
+    L.check(L.lib().ufnd_gemm_bf16_ln(xb.data_ptr(), Wp.data_ptr(), bias.data_ptr(), None, None, of.data_ptr(), M, N, K, K, K, 0, 0, N, act,
+                                      C.byref(ln), L.stream_ptr(x.device)), "gemm_ln")
+    torch.cuda.synchronize()
+    return of, float(guard.cpu())
+
+
+@pytest.mark.parametrize("ratio", [0.0, 1.0, 10.0, 50.0])
+def test_gemm_ln_fold_error_grows_with_the_row_offset(ratio):
+    """The folded LayerNorm on hostile rows: |mean| / std in {0, 1, 10, 50}, outlier columns, gamma / beta spread 10x,
+    against fp32 layer_norm -> linear.  The stated bound (include/ultrafnd_hip.h): error <= (1 + |mean|/std) * 2^-9 of
+    the output scale, times 2 for the fp32 accumulation tail.  The fold guard reports the ratio it saw."""
+    M, N, K = 1024, 3072, 768
+    x, gm, bt, Wf, b = _fold_case(M, N, K, ratio, 7 + int(ratio))
+    of, seen = _run_fold(x, gm, bt, Wf, b)
+    ref = F.layer_norm(x, (K,), gm, bt, 1e-5) @ Wf.t() + b
+    # the materialised path's own error on the same rows, for comparison: fp32 LayerNorm -> bf16 -> GEMM
+    mat = F.layer_norm(x, (K,), gm, bt, 1e-5).bfloat16().float() @ Wf.bfloat16().float().t() + b
+    scale = ref.std().item()
+    e_fold, e_mat = (of - ref).abs().max().item() / scale, (mat - ref).abs().max().item() / scale
+    true_ratio = (x.mean(1).abs() / x.std(1, unbiased=False)).max().item()
+    print(f"|mean|/std {true_ratio:6.2f} (guard {seen:6.2f}): folded max-abs-err {e_fold:.3e} of the output std; materialised {e_mat:.3e}")
+    assert abs(seen - true_ratio) <= 0.02 * max(1.0, true_ratio)
+    assert e_fold <= 2.0 * (1.0 + true_ratio) * 2 ** -9 * 4.0, (e_fold, true_ratio)     # 4 = max / rms of a 3M-element Gaussian tail
+    if ratio <= 1.0:
+        assert e_fold <= 3.0 * max(e_mat, 2 ** -9)      # inside the guard's range the folded form is as good as the materialised one
+
+
+def test_fold_guard_falls_back_to_materialised_layernorm():
+    """An encoder whose residual stream carries a large common-mode offset (embedding LayerNorm bias = 30): the folded
+    pass trips the guard; strict forwards repeat the batch with materialised LayerNorms and stay within the normal
+    feature bound, and the encoder keeps folding off afterwards."""
+    from oracle import encoders_ref as E
+    from ultrafnd_git_amd.encoders import BertTextEncoder
+    w = E.seeded_weights(E.bert_shapes(layers=2, vocab=1000), 81)
+    w["embeddings.LayerNorm.bias"] = w["embeddings.LayerNorm.bias"] + 30.0
+    ids, mask = E.synthetic_tokens(181, 6, 64, vocab=1000)
+    ref = E.text_features(w, ids, mask)
+    enc = BertTextEncoder(layers=2, vocab_size=1000)
+    enc.load_state_dict(w)
+    enc = enc.to(DEV)
+    folded = enc(ids, mask).clone()
+    ratio = enc.fold_ratio()
+    e_folded = (folded.cpu() - ref).abs().max().item()
+    assert enc.fold_ln and ratio > enc.FOLD_GUARD_MAX, ratio
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        strict = enc(ids, mask, strict=True).clone()
+    e_strict = (strict.cpu() - ref).abs().max().item()
+    print(f"offset rows (|mean|/std {ratio:.1f}): folded feature err {e_folded:.3e}, after the fallback {e_strict:.3e}")
+    assert not enc.fold_ln and any("materialised" in str(c.message) for c in caught)
+    assert e_strict <= 4e-3, e_strict
+    # well-behaved encoders never trip it
+    enc2 = BertTextEncoder(layers=2, vocab_size=1000)
+    enc2.load_state_dict(E.seeded_weights(E.bert_shapes(layers=2, vocab=1000), 81))
+    enc2 = enc2.to(DEV)
+    enc2(ids, mask, strict=True)
+    assert enc2.fold_ln and enc2.fold_ratio() == 0.0      # (check_fold reset the guard)

@@ -73,6 +73,91 @@ def test_gemm_bf16(M, N, K, act, use_bias, use_res):
     assert e16 <= (2e-3 + 2 ** -8) * max(scale, 1.0), e16
 
 
+def _exported_tiles():
+    """(id, bm, bn, ln_aware) of every tile built into libultrafnd_hip.so (host-side query, no GPU call)."""
+    L = _lib()
+    out = []
+    for t in range(L.lib().ufnd_gemm_bf16_tile_count()):
+        bm, bn, ln = C.c_int(), C.c_int(), C.c_int()
+        if L.lib().ufnd_gemm_bf16_tile_info(t, C.byref(bm), C.byref(bn), C.byref(ln)):
+            out.append((t, bm.value, bn.value, ln.value))
+    return out
+
+
+def test_gemm_bf16_every_exported_tile():
+    """Every tile a caller can name through ufnd_gemm_bf16_ex / ufnd_gemm_ln.tile_cfg: plain epilogue (bias, GELU,
+    residual, both outputs) on a ragged M, and -- for the LayerNorm-aware tiles -- the folded form and the
+    residual-through-LayerNorm form with row statistics.  Ids outside the library are rejected."""
+    L = _lib()
+    tiles = _exported_tiles()
+    assert len(tiles) >= 4 and {22, 16, 17, 20} <= {t[0] for t in tiles}
+    g = torch.Generator().manual_seed(99)
+    for t, bm, bn, ln_aware in tiles:
+        M, N, K = 2 * bm + 37, 2304, 768              # 2304 = lcm-friendly: divisible by 64, 128, 144, 192, 256 x 9
+        if N % bn:
+            N = bn * 6
+        A = torch.randn(M, K, generator=g).to(DEV).bfloat16()
+        W = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV).bfloat16()
+        bias, res = torch.randn(N, generator=g).to(DEV), torch.randn(M, N, generator=g).to(DEV)
+        ob = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        of = torch.empty(M, N, device=DEV)
+        L.check(L.lib().ufnd_gemm_bf16_ex(A.data_ptr(), W.data_ptr(), bias.data_ptr(), res.data_ptr(), ob.data_ptr(), of.data_ptr(), M, N, K,
+                                          K, K, N, N, N, 1, t, L.stream_ptr(A.device)), f"tile {t}")
+        torch.cuda.synchronize()
+        ref = F.gelu(A.float() @ W.float().t() + bias) + res
+        scale = max(ref.abs().max().item(), 1.0)
+        assert (of - ref).abs().max().item() <= 2e-3 * scale and (ob.float() - ref).abs().max().item() <= (2e-3 + 2 ** -8) * scale, t
+        if not ln_aware:
+            continue
+        # folded LayerNorm of the A operand
+        x = (torch.randn(M, K, generator=g) * 1.5 + 0.2).to(DEV)
+        gm, bt = (1 + 0.2 * torch.randn(K, generator=g)).to(DEV), (0.1 * torch.randn(K, generator=g)).to(DEV)
+        Wf = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+        Wp = (Wf * gm[None, :]).bfloat16()
+        lnp = L.GemmLn()
+        st = _split_stats(x, 24)
+        lnp.a_stats, lnp.colsum, lnp.a_parts, lnp.a_eps, lnp.r_eps, lnp.width, lnp.tile_cfg = st.data_ptr(), Wp.float().sum(1).contiguous().data_ptr(), 24, 1e-5, 1e-5, K, t
+        cs = Wp.float().sum(1).contiguous()
+        lnp.colsum = cs.data_ptr()
+        b2 = (bias + Wf @ bt).contiguous()
+        L.check(L.lib().ufnd_gemm_bf16_ln(x.bfloat16().data_ptr(), Wp.data_ptr(), b2.data_ptr(), None, ob.data_ptr(), of.data_ptr(), M, N, K,
+                                          K, K, 0, N, N, 0, C.byref(lnp), L.stream_ptr(A.device)), f"ln tile {t}")
+        torch.cuda.synchronize()
+        ref = F.layer_norm(x, (K,), gm, bt, 1e-5) @ Wf.t() + bias
+        scale = max(ref.abs().max().item(), 1.0)
+        assert (of - ref).abs().max().item() <= 6e-3 * scale, t
+        # residual through a LayerNorm + row statistics out (N = 768 only: that is where the encoders use it)
+        N2 = 768
+        if N2 % bn == 0:
+            W2 = (torch.randn(N2, K, generator=g) / K ** 0.5).to(DEV).bfloat16()
+            r = (torch.randn(M, N2, generator=g) * 1.5 - 0.2).to(DEV)
+            gm2, bt2, b3 = (1 + 0.2 * torch.randn(N2, generator=g)).to(DEV), (0.1 * torch.randn(N2, generator=g)).to(DEV), torch.randn(N2, generator=g).to(DEV)
+            rs = _split_stats(r, 12)
+            of2, ob2 = torch.empty(M, N2, device=DEV), torch.empty(M, N2, dtype=torch.bfloat16, device=DEV)
+            sto = torch.full((M, N2 // 32, 2), float("nan"), device=DEV)
+            ln2 = L.GemmLn()
+            ln2.r_stats, ln2.r_gamma, ln2.r_beta, ln2.r_parts, ln2.out_stats = rs.data_ptr(), gm2.data_ptr(), bt2.data_ptr(), 12, sto.data_ptr()
+            ln2.a_eps = ln2.r_eps = 1e-12
+            ln2.width, ln2.tile_cfg = N2, t
+            rc = L.lib().ufnd_gemm_bf16_ln(A.data_ptr(), W2.data_ptr(), b3.data_ptr(), r.data_ptr(), ob2.data_ptr(), of2.data_ptr(), M, N2, K,
+                                           K, K, N2, N2, N2, 0, C.byref(ln2), L.stream_ptr(A.device))
+            if rc != 0:          # a tile whose wave columns are not whole 32-column groups has no statistics epilogue
+                assert b"out_stats" in L.lib().ufnd_last_error(), (t, L.lib().ufnd_last_error())
+                continue
+            torch.cuda.synchronize()
+            ref2 = A.float() @ W2.float().t() + b3 + F.layer_norm(r, (N2,), gm2, bt2, 1e-12)
+            sc2 = max(ref2.abs().max().item(), 1.0)
+            assert (of2 - ref2).abs().max().item() <= 2e-3 * sc2, t
+            assert not torch.isnan(sto).any() and (sto - _split_stats(of2, N2 // 32)).abs().max().item() <= 1e-4 * sc2 * sc2 * 32, t
+    # ids that are not part of the library: rejected, nothing launched
+    built = {t[0] for t in tiles}
+    A = torch.zeros(64, 64, dtype=torch.bfloat16, device=DEV)
+    o = torch.zeros(64, 64, device=DEV)
+    for bad in [t for t in range(L.lib().ufnd_gemm_bf16_tile_count()) if t not in built][:3] + [L.lib().ufnd_gemm_bf16_tile_count(), 100, 122, 222]:
+        rc = L.lib().ufnd_gemm_bf16_ex(A.data_ptr(), A.data_ptr(), None, None, None, o.data_ptr(), 64, 64, 64, 64, 64, 0, 0, 64, 0, bad, None)
+        assert rc == 1 and b"not part of this library" in L.lib().ufnd_last_error(), bad
+
+
 def test_gemm_rejects_bad_shapes():
     L = _lib()
     A = torch.zeros(8, 96, dtype=torch.bfloat16, device=DEV)
@@ -251,7 +336,8 @@ def test_text_features_match_third_party(tag):
     feat = enc(ids, mask).cpu().numpy()
     ef = np.abs(feat - z[f"{tag}/features"]).max()
     print(f"{tag}: hidden max-abs-err {eh:.3e}, feature max-abs-err {ef:.3e}")
-    assert ef <= 4e-3 and eh <= 0.15, (ef, eh)
+    # hidden entries are of order 1 after the final LayerNorm; two layers of bf16 GEMMs: 2^-9 * sqrt(8) ~ 6e-3 rms, tail x5
+    assert ef <= 4e-3 and eh <= 3e-2, (ef, eh)
 
 
 @pytest.mark.parametrize("tag", ["vit2_F1", "vit2_F4"])

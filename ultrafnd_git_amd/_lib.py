@@ -68,7 +68,7 @@ class GemmLn(C.Structure):
     """ufnd_gemm_ln: the LayerNorm extras of ufnd_gemm_bf16_ln."""
     _fields_ = [("a_stats", _FP), ("colsum", _FP), ("r_stats", _FP), ("r_gamma", _FP), ("r_beta", _FP), ("out_stats", _FP),
                 ("a_parts", C.c_int), ("r_parts", C.c_int), ("a_eps", C.c_float), ("r_eps", C.c_float), ("width", C.c_int),
-                ("tile_cfg", C.c_int)]
+                ("tile_cfg", C.c_int), ("fold_guard", _FP)]
 
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)

@@ -47,9 +47,15 @@ def _bf16(t: torch.Tensor) -> torch.Tensor:
 class _EncoderBase(nn.Module):
     """Weight store with third-party key names + lazily packed bf16 operands + per-shape buffers."""
 
+    # Largest |mean| / std of a row whose LayerNorm may be folded into the next GEMM.  Folding rounds the UN-normalised
+    # row to bf16, so its error relative to the normalised output is about (1 + |mean|/std) * 2^-9: at 4 it is still
+    # below the bf16 floor of the materialised path; beyond, the encoder falls back to one LayerNorm kernel per LayerNorm.
+    FOLD_GUARD_MAX = 4.0
+
     def __init__(self):
         super().__init__()
         self.tiles = {}
+        self._guard: Optional[torch.Tensor] = None
         self._w: "OrderedDict[str, torch.Tensor]" = OrderedDict()
         self._packed: Optional[dict] = None
         self._bufs: Dict[Tuple, dict] = {}
@@ -116,6 +122,10 @@ class _EncoderBase(nn.Module):
         ln.a_eps = ln.r_eps = eps
         ln.width = self.hidden
         ln.tile_cfg = self.tiles.get(which, -1)
+        if a_stats is not None:
+            if self._guard is None or self._guard.device != A.device:
+                self._guard = torch.zeros(1, dtype=torch.float32, device=A.device)
+            ln.fold_guard = self._guard.data_ptr()
         import ctypes
         L.check(L.lib().ufnd_gemm_bf16_ln(A.data_ptr(), W.data_ptr(), L.ptr(bias), L.ptr(residual), L.ptr(out_bf16),
                                           L.ptr(out_f32), M, N, K, A.stride(0), W.stride(0),
@@ -123,6 +133,26 @@ class _EncoderBase(nn.Module):
                                           out_bf16.stride(0) if out_bf16 is not None else 0,
                                           out_f32.stride(0) if out_f32 is not None else 0, act, ctypes.byref(ln),
                                           L.stream_ptr(A.device)), "ufnd_gemm_bf16_ln")
+
+    def fold_ratio(self) -> float:
+        """Largest |mean| / std over the rows whose LayerNorm has been folded since the last reset (synchronises)."""
+        return 0.0 if self._guard is None else float(self._guard.cpu())
+
+    def check_fold(self, reset: bool = True) -> bool:
+        """The fold guard: True (and folding switched off for every later call, buffers rebuilt) when a folded row
+        was seen whose |mean| / std exceeds FOLD_GUARD_MAX.  The trainer calls it once per epoch; the offline
+        feature builder (`strict=True` forwards) after every batch, re-running the batch unfolded."""
+        r = self.fold_ratio()
+        if reset and self._guard is not None:
+            self._guard.zero_()
+        if self.fold_ln and r > self.FOLD_GUARD_MAX:
+            import warnings
+            warnings.warn(f"{type(self).__name__}: a residual-stream row with |mean|/std = {r:.1f} (> {self.FOLD_GUARD_MAX}) went through a "
+                          "folded LayerNorm; switching to materialised LayerNorms (fold_ln=False)")
+            self.fold_ln = False
+            self._bufs.clear()
+            return True
+        return False
 
     @staticmethod
     def _fold(W, b, gamma, beta):
@@ -280,11 +310,17 @@ class BertTextEncoder(_EncoderBase):
         self._ln(y2, H, prev["g2"], prev["b2n"], b["xb"], b["xf"], M, H, eps)      # last_hidden_state is materialised once
 
     @torch.no_grad()
-    def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, unpad: bool = False) -> torch.Tensor:
+    def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, unpad: bool = False, strict: bool = False) -> torch.Tensor:
         """Batched BERTContextEncoder.encode: (B,L) ids/mask -> (B,768) L2-normalised features.
+        strict=True checks the fold guard after the pass (one host sync) and, if it tripped, repeats the batch with
+        materialised LayerNorms -- for offline feature building; not for hipGraph capture.
         unpad=True runs the encoder over the kept tokens only (packed rows, per-sequence attention): the padded
         positions never reach the pooling (text_blocks.py:82-86), so no returned value changes -- bit-identical for
         prefix masks -- while the work drops with the padding fraction.  Shapes vary per batch: not for hipGraph capture."""
+        if strict and self.fold_ln:
+            out = self.forward(input_ids, attention_mask, unpad=unpad)
+            if not self.check_fold():
+                return out
         if unpad:
             return self._forward_packed(input_ids, attention_mask)
         hid = self.last_hidden_state(input_ids, attention_mask)
@@ -349,7 +385,7 @@ class BertTextEncoder(_EncoderBase):
         parts = torch.zeros(N * Mx, self.hidden, dtype=torch.float32, device=dev)
         for s0 in range(0, rows.numel(), chunk):
             r = rows[s0:s0 + chunk]
-            parts[r] = self.forward(ids[r], mask[r], unpad=unpad)      # (texts are short against max_length: skip the padding)
+            parts[r] = self.forward(ids[r], mask[r], unpad=unpad, strict=True)      # (texts are short against max_length: skip the padding)
         out = torch.empty(N, self.hidden, dtype=torch.float32, device=dev)
         L.check(L.lib().ufnd_field_mean_l2(parts.data_ptr(), valid.data_ptr(), out.data_ptr(), N, Mx, self.hidden,
                                            L.stream_ptr(dev)), "ufnd_field_mean_l2")
@@ -482,10 +518,14 @@ class ClipVisualEncoder(_EncoderBase):
         return b["e"], b
 
     @torch.no_grad()
-    def forward(self, frames: torch.Tensor) -> torch.Tensor:
-        """frames (B,F,3,224,224) or (B,3,224,224) -> (B,512) features."""
+    def forward(self, frames: torch.Tensor, strict: bool = False) -> torch.Tensor:
+        """frames (B,F,3,224,224) or (B,3,224,224) -> (B,512) features.  strict: as BertTextEncoder.forward."""
         if frames.dim() == 4:
             frames = frames[:, None]
+        if strict and self.fold_ln:
+            out = self.forward(frames)
+            if not self.check_fold():
+                return out
         B, Fr = frames.shape[:2]
         e, b = self._run(frames)
         L.check(L.lib().ufnd_l2norm_frames(e.data_ptr(), b["feat"].data_ptr(), B, Fr, self.proj, L.stream_ptr(self.device)),

@@ -699,6 +699,13 @@ class ForensicTrainer:
             ys.append(out["y"].clone())
             p1s.append(out["probs"][:, 1].clone())
             fors.append(f.clone())
+        if is_train and self.cfg.encode_inline:
+            # fold guard of the in-step encoders (encoders.py): a row outside the folded LayerNorm's accuracy range
+            # switches the encoder to materialised LayerNorms; the captured graphs are rebuilt on the next step
+            for enc, key in ((self.text_encoder, "g_text"), (self.visual_encoder, "g_vis")):
+                if enc is not None and enc.check_fold():
+                    for e in self._enc_bufs.values():
+                        e[key] = None
         if not losses and self.world == 1:
             return 0.0, aggregate_epoch_metrics(np.array([], dtype=int), np.array([], dtype=float))
         if not losses:      # an empty evaluation shard still takes part in the gather
