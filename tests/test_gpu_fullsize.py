@@ -170,6 +170,9 @@ def test_fold_guard_falls_back_to_materialised_layernorm():
     from ultrafnd_git_amd.encoders import BertTextEncoder
     w = E.seeded_weights(E.bert_shapes(layers=2, vocab=1000), 81)
     w["embeddings.LayerNorm.bias"] = w["embeddings.LayerNorm.bias"] + 30.0
+    # (random value / output projections would turn the offset into variance: keep layer 0's attention branch small, so
+    #  that the row entering the folded attention.output.LayerNorm is "embedding row + offset")
+    w["encoder.layer.0.attention.output.dense.weight"] = w["encoder.layer.0.attention.output.dense.weight"] * 0.01
     ids, mask = E.synthetic_tokens(181, 6, 64, vocab=1000)
     ref = E.text_features(w, ids, mask)
     enc = BertTextEncoder(layers=2, vocab_size=1000)
