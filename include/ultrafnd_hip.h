@@ -364,12 +364,15 @@ int ufnd_gather_rows(const int64_t* idx, int B, const ufnd_gather_item* items, i
  *   with v^ = visual zero-padded / truncated to D.  w0 is (hidden, 4D+1) stored with row stride
  *   ufnd_temporal_weight_ld(D) (4D+1 rounded up to a multiple of 4, pad zero); w3 (out_dim, hidden).
  *   workspace: ufnd_temporal_workspace_floats(B, D, hidden) floats.
+ *   dropout_p > 0 = the module's train mode: nn.Dropout(p) after the GELU, mask keyed by state->{seed, step} (the
+ *   reference's align() is under torch.inference_mode, which does not switch dropout off, and its cache builder never
+ *   calls .eval()); dropout_p = 0 (state may be NULL) = eval mode.
  * ---------------------------------------------------------------------------------- */
 int ufnd_temporal_weight_ld(int in_dim);
 size_t ufnd_temporal_workspace_floats(int B, int in_dim, int hidden);
 int ufnd_temporal_align(const float* text, const float* visual, const float* w0, const float* b0, const float* w3,
                         const float* b3, float* workspace, float* out, int B, int in_dim, int vis_dim, int hidden,
-                        int out_dim, void* stream);
+                        int out_dim, float dropout_p, const ufnd_step_state* state, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * TemporalSyncNet.forward, the sequence path   src/core_blocks/temporal_blocks.py:141-157, _TinyTCN :16-43

@@ -2,7 +2,10 @@
 
 torch-fp32 restatement of src/core_blocks/temporal_blocks.py:102-140 (+ `_cosine` :10-13):
   v is zero-padded / truncated to the text width D; feat = [t, v, t-v, t*v, cos(t,v)] (4D+1);
-  out = Linear(2*out, out)(GELU(Linear(4D+1, 2*out)(feat)))   (dropout inactive: inference_mode).
+  out = Linear(2*out, out)(Dropout(GELU(Linear(4D+1, 2*out)(feat)))).  This restates the EVAL-mode module (dropout
+  off), which is what the golden pins (make_golden.py calls .eval() first).  torch.inference_mode on the reference's
+  align() does not switch dropout off: in the module's default train mode its Dropout(0.1) is live (the product
+  honours self.training; tests/test_gpu_tier_a.py checks the train-mode mask statistically).
 The reference never trains these weights (random init, fixed projection).  Pinned against the real
 class by tests/golden/make_golden.py -> tests/golden/temporal.npz.
 """

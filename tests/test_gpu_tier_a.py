@@ -194,7 +194,7 @@ def test_temporal_align_matches_reference():
     z = load_npz("temporal.npz")
     net = TemporalSyncNet(in_dim=768, out_dim=256)
     net.load_state_dict(T.seeded_weights(int(z["weight_seed"])))
-    net = net.to("cuda")
+    net = net.to("cuda").eval()                    # the golden was minted from the reference in eval mode (dropout off)
     t, v = torch.from_numpy(z["t"]), torch.from_numpy(z["v"])
     got = net.align_batch(t, v).cpu().numpy()
     err = np.abs(got - z["out"]).max()
@@ -203,6 +203,40 @@ def test_temporal_align_matches_reference():
     assert err <= 2e-6 and np.abs(one - z["out_self"]).max() <= 2e-6 and one.dtype == np.float32
     wide = net.align_batch(t, torch.cat([torch.from_numpy(z["t"]), torch.ones(6, 40)], dim=1))    # Dv > D: truncated
     assert np.abs(wide.cpu().numpy() - T.align(T.seeded_weights(51), t, t).numpy()).max() <= 2e-6
+
+
+def test_temporal_align_train_mode_applies_the_projections_dropout():
+    """The reference's align() is under torch.inference_mode, which does not switch dropout off, and the cache builder
+    never calls .eval(): in (default) train mode the Dropout(0.1) between the two Linears is live.  With an identity-like
+    second Linear the output shows the mask: every hidden unit is either dropped or scaled by 1 / (1 - p); the keep
+    fraction is 1 - p; consecutive calls draw different masks; eval mode is deterministic."""
+    from ultrafnd_git_amd.temporal import TemporalSyncNet
+    torch.manual_seed(3)
+    net = TemporalSyncNet(in_dim=768, out_dim=256)
+    with torch.no_grad():
+        net.proj[3].weight.zero_()
+        net.proj[3].weight[:, :256].copy_(torch.eye(256))           # out[:, i] = dropped hidden unit i
+        net.proj[3].bias.zero_()
+    net = net.to("cuda")
+    g = torch.Generator().manual_seed(4)
+    t, v = torch.randn(64, 768, generator=g), torch.randn(64, 512, generator=g)
+    assert net.training
+    a, b = net.align_batch(t, v).clone(), net.align_batch(t, v).clone()
+    net.eval()
+    e1, e2 = net.align_batch(t, v).clone(), net.align_batch(t, v).clone()
+    assert torch.equal(e1, e2)
+    p = net.proj[2].p
+    live = e1.abs() > 1e-4
+    for x in (a, b):
+        ratio = (x / e1)[live]
+        kept = ratio.abs() > 0.5
+        assert (ratio[kept] - 1.0 / (1.0 - p)).abs().max().item() <= 1e-5 and (ratio[~kept]).abs().max().item() == 0.0
+        frac = kept.float().mean().item()
+        assert abs(frac - (1.0 - p)) <= 4.0 * (p * (1 - p) / kept.numel()) ** 0.5 + 1e-3, frac
+    assert not torch.equal(a, b)                                    # a fresh mask per call
+    net.train()
+    one = net.align(t[0].numpy(), v[0].numpy())
+    assert one.shape == (256,) and one.dtype == np.float32
 
 
 DEV = "cuda"

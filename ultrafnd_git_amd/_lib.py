@@ -139,7 +139,7 @@ def _declare_encoders(lib: C.CDLL) -> None:
         "ufnd_device_cu_count": [],
         "ufnd_l2norm_frames": [P, P, I, I, I, P],
         "ufnd_field_mean_l2": [P, P, P, I, I, I, P],
-        "ufnd_temporal_align": [P] * 8 + [I] * 5 + [P],
+        "ufnd_temporal_align": [P] * 8 + [I] * 5 + [F, P, P],
     }
     for name, argtypes in sigs.items():
         fn = getattr(lib, name)

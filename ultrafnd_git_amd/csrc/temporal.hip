@@ -1,6 +1,8 @@
 // TemporalSyncNet.align (src/core_blocks/temporal_blocks.py:102-140), batched:
 //   feat = [t, v^, t - v^, t * v^, cos(t, v^)]  (v^ = v zero-padded / truncated to D), 4D+1 wide
-//   out  = W3 GELU(W0 feat + b0) + b3            fp32, inference only (the reference never trains it)
+//   out  = W3 drop(GELU(W0 feat + b0)) + b3      fp32, forward only (the reference never trains it).  The reference's
+//          align() is decorated with torch.inference_mode, which switches autograd off, NOT dropout: the module's
+//          Dropout(0.1) is live whenever the module is in its default train mode (the cache builder never calls .eval())
 // One wave per sample builds feat (row stride padded to a multiple of 4, pad columns zero); the two
 // Linears run on the fp32 MFMA skinny GEMM (gemm_f32.hip) -- W0 must be stored with that same padded
 // row stride (ufnd_temporal_weight_ld) because 4D+1 is odd.
@@ -42,12 +44,13 @@ extern "C" size_t ufnd_temporal_workspace_floats(int B, int in_dim, int hidden) 
 
 extern "C" int ufnd_temporal_align(const float* text, const float* visual, const float* w0, const float* b0, const float* w3,
                                    const float* b3, float* workspace, float* out, int B, int in_dim, int vis_dim, int hidden,
-                                   int out_dim, void* stream_) {
+                                   int out_dim, float dropout_p, const ufnd_step_state* state, void* stream_) {
   UFND_REQUIRE(text && visual && w0 && b0 && w3 && b3 && workspace && out, "temporal_align: null argument");
   UFND_REQUIRE(B >= 1 && in_dim >= 1 && vis_dim >= 1 && hidden % 32 == 0 && out_dim % 32 == 0,
                "temporal_align: B=%d D=%d Dv=%d hidden=%d out=%d (hidden/out multiples of 32)", B, in_dim, vis_dim, hidden, out_dim);
   UFND_REQUIRE(ufnd_aligned(workspace, 16) && ufnd_aligned(w0, 16) && ufnd_aligned(w3, 16) && ufnd_aligned(out, 16),
                "temporal_align: 16-B alignment required");
+  UFND_REQUIRE(dropout_p >= 0.0f && dropout_p < 1.0f && (dropout_p == 0.0f || state), "temporal_align: dropout_p=%g needs a step state", dropout_p);
   hipStream_t stream = (hipStream_t)stream_;
   const int ldf = ufnd_temporal_weight_ld(in_dim);
   float* feat = workspace;
@@ -56,8 +59,9 @@ extern "C" int ufnd_temporal_align(const float* text, const float* visual, const
                      vis_dim < in_dim ? vis_dim : in_dim, feat, ldf);
   UFND_CHECK_LAUNCH();
   // note: visual rows are read with their own stride vis_dim; columns >= in_dim are ignored (truncate)
-  NtProb p0{feat, w0, b0, h, nullptr, B, hidden, 4 * in_dim + 1, ldf, ldf, hidden, 0, 1, 0.0f, 0, 1};
-  int rc = launch_nt(&p0, 1, nullptr, stream);
+  constexpr uint32_t LAYER_ALIGN = 21;       // dropout stream tag (mask keyed by state->{seed, step})
+  NtProb p0{feat, w0, b0, h, nullptr, B, hidden, 4 * in_dim + 1, ldf, ldf, hidden, 0, 1, dropout_p, LAYER_ALIGN, 1};
+  int rc = launch_nt(&p0, 1, dropout_p > 0.0f ? state : nullptr, stream);
   if (rc != UFND_OK) return rc;
   NtProb p1{h, w3, b3, out, nullptr, B, out_dim, hidden, hidden, hidden, out_dim, 0, 0, 0.0f, 0, 1};
   return launch_nt(&p1, 1, nullptr, stream);

@@ -2,8 +2,11 @@
 (src/core_blocks/temporal_blocks.py:47-140): `align(text_vec, visual_vec) -> np.ndarray[out_dim]`
 produces the `temporal (N,256)` input of the fusion step (fakesv_dataset.py:176).  Same
 constructor arguments and `state_dict` keys (`proj.{0,3}.{weight,bias}`); the weights are never
-trained in the reference (random init, inference_mode), so this is a fixed random projection.
-`align_batch` is the batched device-to-device form used inside the step.
+trained in the reference (random init), so this is a fixed random projection.  `align_batch` is the batched
+device-to-device form used inside the step.  Like the reference's, `align` honours `self.training`: its
+`torch.inference_mode` decorator switches autograd off, not dropout, and the cache builder never calls `.eval()`, so
+the projection's Dropout(0.1) is live there (mask from this module's own counter-based stream); call `.eval()` for
+the deterministic projection the golden fixtures pin.
 
 `use_tcn=True` adds the optional sequence path (:16-43 `_TinyTCN`, :141-157 `forward(text_seq, vis_seq)`): dilated
 Conv1d -> BatchNorm1d -> GELU -> dropout blocks with residuals, mean+max pooling over time and a Linear head, run by
@@ -65,12 +68,14 @@ class TemporalSyncNet(nn.Module):
             p.requires_grad_(False)
         self._packed = None
         self._ws: Dict[int, torch.Tensor] = {}
+        self._align_state = None
 
     def _apply(self, fn, recurse=True):
         out = super()._apply(fn, recurse)
         self._packed = None
         self._seq_packed = None
         self._ws.clear()
+        self._align_state = None
         return out
 
     def load_state_dict(self, *a, **kw):
@@ -103,9 +108,17 @@ class TemporalSyncNet(nn.Module):
             n = L.lib().ufnd_temporal_workspace_floats(B, self.in_dim, 2 * self.out_dim)
             self._ws[B] = torch.empty(n, dtype=torch.float32, device=dev)
         out = torch.empty(B, self.out_dim, dtype=torch.float32, device=dev)
+        p = float(self.proj[2].p) if self.training else 0.0
+        st = None
+        if p > 0.0:                  # device-resident counter: every call draws a fresh mask (stream-ordered, no host copy)
+            if self._align_state is None or self._align_state.device != dev:
+                self._align_state = StepStateBuffer(dev, seed=self._seq_seed ^ 0x616C_6967_6E)
+            st = self._align_state
         L.check(L.lib().ufnd_temporal_align(t.data_ptr(), v.data_ptr(), w0.data_ptr(), b0.data_ptr(), w3.data_ptr(), b3.data_ptr(),
                                             self._ws[B].data_ptr(), out.data_ptr(), B, self.in_dim, v.shape[1], 2 * self.out_dim,
-                                            self.out_dim, L.stream_ptr(dev)), "ufnd_temporal_align")
+                                            self.out_dim, p, st.ptr if st is not None else None, L.stream_ptr(dev)), "ufnd_temporal_align")
+        if st is not None:
+            st.advance()
         return out
 
     def align(self, text_vec: Union[np.ndarray, torch.Tensor], visual_vec: Union[np.ndarray, torch.Tensor]) -> np.ndarray:
