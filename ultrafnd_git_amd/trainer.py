@@ -658,6 +658,7 @@ class ForensicTrainer:
         marker = gaps[len(gaps) // 4] if gaps else 0.0
         self.last_marker_us = marker * 1e3
         total = sum(max(0.0, e0.elapsed_time(e1) - marker) for e0, e1 in events)
+        self.last_raw_interval_us = sum(e0.elapsed_time(e1) for e0, e1 in events) / max(1, len(events)) * 1e3
         self.last_gemm_by_shape = {}
         for (e0, e1), shp in zip(events, shapes):
             d = self.last_gemm_by_shape.setdefault("x".join(map(str, shp)), [0, 0.0])
