@@ -252,8 +252,10 @@ int ufnd_gemm_bf16_ex(const void* A, const void* W, const float* bias, const flo
  * Accuracy of the folded form.  The consumer multiplies the bf16 rounding of the UN-normalised row, so a common-mode
  * offset of the row is rounded before it is subtracted: relative to the normalised output the error is about
  * (1 + |mean| / std) * 2^-9 (measured: tests/test_gpu_tier_b.py::test_gemm_ln_fold_error_grows_with_the_row_offset).
- * Rows of trained BERT / CLIP streams have |mean| / std well below 1; fold_guard publishes the largest ratio seen so
- * that a caller can fall back to a materialised LayerNorm (ufnd_layernorm + ufnd_gemm_bf16) when it is not.
+ * Rows of trained BERT / CLIP streams have |mean| / std well below 1; ufnd_ln_fold_guard (below) reports the largest
+ * ratio in a statistics buffer so that a caller can fall back to a materialised LayerNorm (ufnd_layernorm +
+ * ufnd_gemm_bf16) when it is not.  (It is a kernel of its own: an atomic inside the GEMM -- tried -- sits in front of
+ * the K loop's counted vmcnt waits and cost 10 us per launch.)
  * Replaces nn.LayerNorm + nn.Linear pairs of the third-party encoders (transformers modeling_bert.py
  * BertSelfOutput / BertOutput, modeling_clip.py CLIPEncoderLayer) behind text_blocks.py:79. */
 typedef struct ufnd_gemm_ln {
@@ -267,7 +269,6 @@ typedef struct ufnd_gemm_ln {
   float a_eps, r_eps;
   int width;
   int tile_cfg; /* < 0: automatic; otherwise a LayerNorm-aware tile id (ufnd_gemm_bf16_tile_info) */
-  float* fold_guard; /* optional (a_stats calls): *fold_guard = max(*fold_guard, |mean| * rstd of every row), see below */
 } ufnd_gemm_ln;
 int ufnd_gemm_bf16_ln(const void* A, const void* W, const float* bias, const float* residual, void* out_bf16,
                       float* out_f32, int M, int N, int K, int lda, int ldw, int ldr, int ldo, int ldf, int act,
@@ -275,6 +276,10 @@ int ufnd_gemm_bf16_ln(const void* A, const void* W, const float* bias, const flo
 /* Number of {sum, sumsq} partials per row that ufnd_gemm_bf16_ln writes to out_stats for this shape
  * (0 = the shape's tile has no statistics epilogue). */
 int ufnd_gemm_bf16_stat_parts(int M, int N, int K);
+
+/* *guard = max(*guard, max over rows of |mean| * rstd) for the M rows of a statistics buffer (M, parts, 2) as
+ * ufnd_gemm_bf16_ln writes and reads them (partial {sum, sumsq}; statistics over `width` elements). */
+int ufnd_ln_fold_guard(const float* stats, int M, int parts, int width, float eps, float* guard, void* stream);
 
 /* The tile table of this library: ids 0 .. ufnd_gemm_bf16_tile_count()-1; ufnd_gemm_bf16_tile_info returns 1 and the
  * block tile (rows x columns) of a tile that is built into the library (ln_aware: usable by ufnd_gemm_bf16_ln), 0 for

@@ -68,7 +68,7 @@ class GemmLn(C.Structure):
     """ufnd_gemm_ln: the LayerNorm extras of ufnd_gemm_bf16_ln."""
     _fields_ = [("a_stats", _FP), ("colsum", _FP), ("r_stats", _FP), ("r_gamma", _FP), ("r_beta", _FP), ("out_stats", _FP),
                 ("a_parts", C.c_int), ("r_parts", C.c_int), ("a_eps", C.c_float), ("r_eps", C.c_float), ("width", C.c_int),
-                ("tile_cfg", C.c_int), ("fold_guard", _FP)]
+                ("tile_cfg", C.c_int)]
 
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
@@ -132,6 +132,7 @@ def _declare_encoders(lib: C.CDLL) -> None:
         "ufnd_vit_assemble": [P] * 8 + [I, I, I, F, P],
         "ufnd_gemm_bf16_ln": [P] * 6 + [I] * 9 + [C.POINTER(GemmLn), P],
         "ufnd_gemm_bf16_stat_parts": [I, I, I],
+        "ufnd_ln_fold_guard": [P, I, I, I, F, P, P],
         "ufnd_gemm_bf16_tile_count": [],
         "ufnd_gemm_bf16_tile_info": [I, C.POINTER(I), C.POINTER(I), C.POINTER(I)],
         "ufnd_stream_create_cu_mask": [C.POINTER(C.c_uint32), I, C.POINTER(P)],

@@ -367,3 +367,34 @@ extern "C" int ufnd_field_mean_l2(const float* parts, const int32_t* valid, floa
   UFND_CHECK_LAUNCH();
   return UFND_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Fold guard: the largest |mean| / std among the rows of a LayerNorm-statistics buffer (see ufnd_gemm_bf16_ln).
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void ln_fold_guard_kernel(const float* stats, int M, int parts, float inv_h, float eps, float* guard) {
+  __shared__ float sh[4];
+  float worst = 0.0f;
+  for (int row = blockIdx.x * 256 + threadIdx.x; row < M; row += gridDim.x * 256) {
+    const float* p = stats + (size_t)row * parts * 2;
+    float sm = 0.0f, sq = 0.0f;
+    for (int i = 0; i < parts; ++i) { sm += p[2 * i]; sq += p[2 * i + 1]; }
+    const float mean = sm * inv_h;
+    const float var = fmaxf(sq * inv_h - mean * mean, 0.0f);
+    worst = fmaxf(worst, fabsf(mean) * rsqrtf(var + eps));
+  }
+  worst = wave_max(worst);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = worst;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicMax(reinterpret_cast<int*>(guard), __float_as_int(fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]))));   // non-negative floats order like ints
+}
+}  // namespace
+
+extern "C" int ufnd_ln_fold_guard(const float* stats, int M, int parts, int width, float eps, float* guard, void* stream_) {
+  UFND_REQUIRE(stats && guard && M >= 1 && parts >= 1 && width >= 1, "ln_fold_guard: bad argument");
+  const int blocks = ufnd_cdiv(M, 256) < 64 ? ufnd_cdiv(M, 256) : 64;
+  hipLaunchKernelGGL(ln_fold_guard_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, stats, M, parts, 1.0f / (float)width, eps, guard);
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}

@@ -72,7 +72,6 @@ extern "C" int ufnd_gemm_bf16_ln(const void* A, const void* W, const float* bias
   UFND_REQUIRE(!(ln->a_stats && ln->r_stats), "gemm_bf16_ln: a_stats and r_stats are mutually exclusive");
   UFND_REQUIRE(ln->a_stats || act == UFND_ACT_NONE, "gemm_bf16_ln: an activation is only fused together with a folded LayerNorm (a_stats)");
   UFND_REQUIRE(ln->width > 0, "gemm_bf16_ln: width (the LayerNorm dimension) must be positive");
-  UFND_REQUIRE(!ln->fold_guard || ufnd_aligned(ln->fold_guard, 4), "gemm_bf16_ln: fold_guard alignment");
   if (ln->a_stats) {
     UFND_REQUIRE(ln->colsum && ufnd_aligned(ln->colsum, 16) && ufnd_aligned(ln->a_stats, 16), "gemm_bf16_ln: colsum / a_stats alignment");
     UFND_REQUIRE(ln->a_parts >= 2 && ln->a_parts <= 24 && ln->a_parts % 2 == 0, "gemm_bf16_ln: a_parts=%d (even, 2..24)", ln->a_parts);
@@ -92,7 +91,6 @@ extern "C" int ufnd_gemm_bf16_ln(const void* A, const void* W, const float* bias
   a.a_stats = ln->a_stats; a.colsum = ln->colsum; a.r_stats = ln->r_stats; a.r_gamma = ln->r_gamma; a.r_beta = ln->r_beta;
   a.out_stats = ln->out_stats; a.a_parts = ln->a_parts; a.r_parts = ln->r_parts; a.a_eps = ln->a_eps; a.r_eps = ln->r_eps;
   a.inv_h = 1.0f / (float)ln->width;
-  a.guard = ln->fold_guard;
   int rc = launch_cfg(cfg, 4, a, (hipStream_t)stream_);
   if (rc != UFND_OK) return rc;
   UFND_CHECK_LAUNCH();

@@ -51,7 +51,6 @@ struct GemmArgs {
   float* out_stats;      // (M, N / 32, 2): partial {sum, sumsq} of the fp32 output rows, one per aligned 32 columns
   int a_parts, r_parts;
   float a_eps, r_eps, inv_h;   // inv_h = 1 / (row width the statistics are over)
-  float* guard;          // optional: running maximum of |mean| * rstd over the rows whose LayerNorm was folded (a_stats)
 };
 
 __device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst) {
@@ -264,13 +263,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
       const float var = fmaxf(__fmaf_rn(-mean, mean, __fmul_rn(sq, a.inv_h)), 0.f);
       const float rstd = __builtin_amdgcn_rsqf(__fadd_rn(var, a.a_stats ? a.a_eps : a.r_eps));   // v_rsq_f32 (1 ulp, the same instruction in every tile shape)
       if (threadIdx.x % TPR == 0) st_lds[threadIdx.x / TPR] = f32x2{mean, rstd};
-      // Folding multiplies the bf16 rounding of the UN-normalised row: its error relative to the normalised output
-      // grows like |mean| / std * 2^-9 (a common-mode offset is rounded before it is subtracted).  The largest ratio
-      // seen is published so that the host can fall back to a materialised LayerNorm (encoders.py, fold guard).
-      if (a.guard && a.a_stats) {
-        const float ratio = wave_max(fabsf(mean) * rstd);
-        if (lane == 0) atomicMax(reinterpret_cast<int*>(a.guard), __float_as_int(ratio));   // (non-negative floats order like ints)
-      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   }

@@ -56,6 +56,7 @@ class _EncoderBase(nn.Module):
         super().__init__()
         self.tiles = {}
         self._guard: Optional[torch.Tensor] = None
+        self.guarded = False          # True while a pass also evaluates the fold guard (one tiny kernel per folded LayerNorm)
         self._w: "OrderedDict[str, torch.Tensor]" = OrderedDict()
         self._packed: Optional[dict] = None
         self._bufs: Dict[Tuple, dict] = {}
@@ -122,10 +123,6 @@ class _EncoderBase(nn.Module):
         ln.a_eps = ln.r_eps = eps
         ln.width = self.hidden
         ln.tile_cfg = self.tiles.get(which, -1)
-        if a_stats is not None:
-            if self._guard is None or self._guard.device != A.device:
-                self._guard = torch.zeros(1, dtype=torch.float32, device=A.device)
-            ln.fold_guard = self._guard.data_ptr()
         import ctypes
         L.check(L.lib().ufnd_gemm_bf16_ln(A.data_ptr(), W.data_ptr(), L.ptr(bias), L.ptr(residual), L.ptr(out_bf16),
                                           L.ptr(out_f32), M, N, K, A.stride(0), W.stride(0),
@@ -133,15 +130,24 @@ class _EncoderBase(nn.Module):
                                           out_bf16.stride(0) if out_bf16 is not None else 0,
                                           out_f32.stride(0) if out_f32 is not None else 0, act, ctypes.byref(ln),
                                           L.stream_ptr(A.device)), "ufnd_gemm_bf16_ln")
+        if self.guarded and a_stats is not None:
+            # a guarded pass (strict forwards, the trainer's once-per-epoch check) looks at every statistics buffer a
+            # folded LayerNorm consumes, right where it is consumed
+            if self._guard is None or self._guard.device != A.device:
+                self._guard = torch.zeros(1, dtype=torch.float32, device=A.device)
+            L.check(L.lib().ufnd_ln_fold_guard(a_stats.data_ptr(), M, a_stats.shape[1], self.hidden, eps, self._guard.data_ptr(),
+                                               L.stream_ptr(A.device)), "ufnd_ln_fold_guard")
 
     def fold_ratio(self) -> float:
-        """Largest |mean| / std over the rows whose LayerNorm has been folded since the last reset (synchronises)."""
+        """Largest |mean| / std over the rows whose LayerNorm was folded in the GUARDED passes since the last reset
+        (synchronises)."""
         return 0.0 if self._guard is None else float(self._guard.cpu())
 
     def check_fold(self, reset: bool = True) -> bool:
-        """The fold guard: True (and folding switched off for every later call, buffers rebuilt) when a folded row
-        was seen whose |mean| / std exceeds FOLD_GUARD_MAX.  The trainer calls it once per epoch; the offline
-        feature builder (`strict=True` forwards) after every batch, re-running the batch unfolded."""
+        """The fold guard: True (and folding switched off for every later call, buffers rebuilt) when a guarded pass saw
+        a folded row whose |mean| / std exceeds FOLD_GUARD_MAX.  Guarded passes: every `strict=True` forward (the offline
+        feature builder: checked after each batch, which is then repeated unfolded) and one pass per epoch of the
+        trainer (`guarded_pass`; the ratio is a property of the weights much more than of one input)."""
         r = self.fold_ratio()
         if reset and self._guard is not None:
             self._guard.zero_()
@@ -153,6 +159,17 @@ class _EncoderBase(nn.Module):
             self._bufs.clear()
             return True
         return False
+
+    def guarded_pass(self, *inputs) -> bool:
+        """One eager forward over `inputs` with the guard evaluated, then check_fold(): the trainer's per-epoch check."""
+        if not self.fold_ln:
+            return False
+        self.guarded = True
+        try:
+            self.forward(*inputs)
+        finally:
+            self.guarded = False
+        return self.check_fold()
 
     @staticmethod
     def _fold(W, b, gamma, beta):
@@ -318,7 +335,11 @@ class BertTextEncoder(_EncoderBase):
         positions never reach the pooling (text_blocks.py:82-86), so no returned value changes -- bit-identical for
         prefix masks -- while the work drops with the padding fraction.  Shapes vary per batch: not for hipGraph capture."""
         if strict and self.fold_ln:
-            out = self.forward(input_ids, attention_mask, unpad=unpad)
+            self.guarded = True
+            try:
+                out = self.forward(input_ids, attention_mask, unpad=unpad)
+            finally:
+                self.guarded = False
             if not self.check_fold():
                 return out
         if unpad:
@@ -523,7 +544,11 @@ class ClipVisualEncoder(_EncoderBase):
         if frames.dim() == 4:
             frames = frames[:, None]
         if strict and self.fold_ln:
-            out = self.forward(frames)
+            self.guarded = True
+            try:
+                out = self.forward(frames)
+            finally:
+                self.guarded = False
             if not self.check_fold():
                 return out
         B, Fr = frames.shape[:2]

@@ -701,12 +701,14 @@ class ForensicTrainer:
             p1s.append(out["probs"][:, 1].clone())
             fors.append(f.clone())
         if is_train and self.cfg.encode_inline:
-            # fold guard of the in-step encoders (encoders.py): a row outside the folded LayerNorm's accuracy range
-            # switches the encoder to materialised LayerNorms; the captured graphs are rebuilt on the next step
-            for enc, key in ((self.text_encoder, "g_text"), (self.visual_encoder, "g_vis")):
-                if enc is not None and enc.check_fold():
-                    for e in self._enc_bufs.values():
-                        e[key] = None
+            # fold guard of the in-step encoders (encoders.py): one eager, guarded pass per epoch over the inputs of the
+            # last batch; a row outside the folded LayerNorm's accuracy range switches that encoder to materialised
+            # LayerNorms, and its captured graph is rebuilt on the next step
+            for e in list(self._enc_bufs.values()):
+                for enc, key, args in ((self.text_encoder, "g_text", (e["ids"], e["mask"])), (self.visual_encoder, "g_vis", (e["frames"],))):
+                    if enc is not None and enc.guarded_pass(*args):
+                        for e2 in self._enc_bufs.values():
+                            e2[key] = None
         if not losses and self.world == 1:
             return 0.0, aggregate_epoch_metrics(np.array([], dtype=int), np.array([], dtype=float))
         if not losses:      # an empty evaluation shard still takes part in the gather
