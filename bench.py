@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--cu-split", type=str, default=None, help="compute units of the text,visual encoder streams, e.g. 192,64 (0 = ordinary streams)")
     ap.add_argument("--text-tiles", type=str, default=None, help="experiments: GEMM tile ids of the text encoder, e.g. qkv=22,out=16,ffn1=22,ffn2=16")
     ap.add_argument("--vis-tiles", type=str, default=None, help="experiments: GEMM tile ids of the visual encoder")
+    ap.add_argument("--no-fuse-attn", action="store_true", help="text encoder: Q/K/V projection and attention as two launches per layer")
     ap.add_argument("--head-only", action="store_true",
                     help="secondary measurement: the reference's actual training mode (cached features, no encoders in the step)")
     args = ap.parse_args()
@@ -219,6 +220,7 @@ def main():
         split = tuple(int(x) for x in args.cu_split.split(","))
     cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir="/tmp/ufnd_bench", batch_size=B, device=str(dev),
                       use_graph=not args.no_graph, encode_inline=True, seed=42, cu_split=split)
+    tenc.fuse_qkv_attention = not args.no_fuse_attn
     for enc, spec in ((tenc, args.text_tiles), (venc, args.vis_tiles)):
         if spec:
             enc.tiles = {k: int(v) for k, v in (kv.split("=") for kv in spec.split(","))}

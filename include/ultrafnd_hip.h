@@ -301,6 +301,17 @@ int ufnd_layernorm(const float* x, int ldx, const float* gamma, const float* bet
 int ufnd_attention_bf16(const void* qkv, const int32_t* key_mask, void* ctx, int B, int L, int heads,
                         void* stream);
 
+/* BertSelfAttention of one layer in ONE launch, for 128-token samples: the fused Q/K/V projection of X (B*128, H) bf16
+ * with the stacked weight Wqkv (3H, H) / bias (3H) -- optionally of LayerNorm(X) folded exactly as ufnd_gemm_bf16_ln
+ * does (ln != NULL with a_stats / colsum / a_parts / a_eps / width; the other fields are ignored) -- followed by
+ * ufnd_attention_bf16 on the result, without the (tokens, 3H) round trip through HBM: one workgroup computes one
+ * sample's Q | K | V for two heads (a 128 x 384 x H tile), rounds them to bf16 into LDS and runs their attention.
+ * Same operations in the same order as the two-launch form: ctx (B*128, H) bf16 is bit-identical to it.
+ * L must be 128, heads even; other shapes use the two-launch form.
+ * Replaces modeling_bert.py BertSelfAttention (query / key / value Linears + eager attention) behind text_blocks.py:79. */
+int ufnd_qkv_attention_bf16(const void* X, const void* Wqkv, const float* bqkv, const int32_t* key_mask, void* ctx, int B, int L,
+                            int heads, int ldx, int ldw, const ufnd_gemm_ln* ln, void* stream);
+
 /* Packed (un-padded) forms: the tokens a padding mask keeps, concatenated over the batch (T rows; sequence b owns
  * rows cu_seqlens[b] .. cu_seqlens[b+1]; pos_ids (T) = each token's position in its sequence).  HF BertModel computes
  * the padded positions too (text_blocks.py:71-79 pads every string to max_length) and the pooling then ignores them

@@ -445,6 +445,78 @@ def test_end_to_end_logit_error():
     assert err <= 1e-3, err
 
 
+@pytest.mark.parametrize("with_ln", [False, True])
+def test_fused_qkv_attention_kernel_is_bit_identical_to_gemm_plus_attention(with_ln):
+    """ufnd_qkv_attention_bf16 (one launch: projection of one sample x two heads, bf16 rounding into LDS, attention) against
+    ufnd_gemm_bf16[_ln] + ufnd_attention_bf16 on the same operands: every ctx element identical; masks incl. a fully
+    masked sample and a one-token sample; an odd sample count (198 workgroups)."""
+    L = _lib()
+    B, Lq, heads, H = 33, 128, 12, 768
+    g = torch.Generator().manual_seed(17)
+    x = (torch.randn(B * Lq, H, generator=g) * 1.3 + 0.1).to(DEV)
+    Wf = (torch.randn(3 * H, H, generator=g) / H ** 0.5).to(DEV)
+    bias = (0.1 * torch.randn(3 * H, generator=g)).to(DEV)
+    lens = torch.randint(1, Lq + 1, (B,), generator=g)
+    lens[0], lens[1], lens[2] = Lq, 1, 0
+    mask = (torch.arange(Lq)[None] < lens[:, None]).to(torch.int32).to(DEV).contiguous()
+    ln = None
+    if with_ln:
+        gm, bt = (1 + 0.2 * torch.randn(H, generator=g)).to(DEV), (0.1 * torch.randn(H, generator=g)).to(DEV)
+        W = (Wf * gm[None, :]).bfloat16()
+        cs = W.float().sum(1).contiguous()
+        b2 = (bias + Wf @ bt).contiguous()
+        st = _split_stats(x, 24)
+        ln = L.GemmLn()
+        ln.a_stats, ln.colsum, ln.a_parts, ln.a_eps, ln.r_eps, ln.width = st.data_ptr(), cs.data_ptr(), 24, 1e-12, 1e-12, H
+    else:
+        W, b2 = Wf.bfloat16(), bias
+    xb = x.bfloat16()
+    qkv = torch.empty(B * Lq, 3 * H, dtype=torch.bfloat16, device=DEV)
+    ctx_ref = torch.empty(B * Lq, H, dtype=torch.bfloat16, device=DEV)
+    ctx = torch.full((B * Lq, H), float("nan"), dtype=torch.bfloat16, device=DEV)
+    s = L.stream_ptr(x.device)
+    if with_ln:
+        L.check(L.lib().ufnd_gemm_bf16_ln(xb.data_ptr(), W.data_ptr(), b2.data_ptr(), None, qkv.data_ptr(), None, B * Lq, 3 * H, H, H, H, 0, 3 * H, 0, 0,
+                                          C.byref(ln), s), "gemm_ln")
+    else:
+        L.check(L.lib().ufnd_gemm_bf16(xb.data_ptr(), W.data_ptr(), b2.data_ptr(), None, qkv.data_ptr(), None, B * Lq, 3 * H, H, H, H, 0, 3 * H, 0, 0, s), "gemm")
+    L.check(L.lib().ufnd_attention_bf16(qkv.data_ptr(), mask.data_ptr(), ctx_ref.data_ptr(), B, Lq, heads, s), "attention")
+    L.check(L.lib().ufnd_qkv_attention_bf16(xb.data_ptr(), W.data_ptr(), b2.data_ptr(), mask.data_ptr(), ctx.data_ptr(), B, Lq, heads, H, H,
+                                            C.byref(ln) if ln is not None else None, s), "qkv_attention")
+    torch.cuda.synchronize()
+    assert torch.isfinite(ctx.float()).all()
+    assert torch.equal(ctx, ctx_ref), (ctx.float() - ctx_ref.float()).abs().max().item()
+    # no mask at all == an all-ones mask
+    ctx2 = torch.empty_like(ctx)
+    ones = torch.ones_like(mask)
+    L.check(L.lib().ufnd_qkv_attention_bf16(xb.data_ptr(), W.data_ptr(), b2.data_ptr(), None, ctx2.data_ptr(), B, Lq, heads, H, H,
+                                            C.byref(ln) if ln is not None else None, s), "qkv_attention")
+    L.check(L.lib().ufnd_qkv_attention_bf16(xb.data_ptr(), W.data_ptr(), b2.data_ptr(), ones.data_ptr(), ctx.data_ptr(), B, Lq, heads, H, H,
+                                            C.byref(ln) if ln is not None else None, s), "qkv_attention")
+    torch.cuda.synchronize()
+    assert torch.equal(ctx, ctx2)
+    # shapes the fused kernel is not built for are refused (the encoder then uses the two-launch form)
+    rc = L.lib().ufnd_qkv_attention_bf16(xb.data_ptr(), W.data_ptr(), b2.data_ptr(), None, ctx.data_ptr(), B, 64, heads, H, H, None, s)
+    assert rc == 1 and b"128-token" in L.lib().ufnd_last_error()
+
+
+@pytest.mark.parametrize("fold", [True, False])
+def test_text_encoder_with_fused_attention_is_bit_identical(fold):
+    from oracle import encoders_ref as E
+    from ultrafnd_git_amd.encoders import BertTextEncoder
+    wt = E.seeded_weights(E.bert_shapes(layers=3, vocab=1000), 73)
+    enc = BertTextEncoder(layers=3, vocab_size=1000, fold_ln=fold)
+    enc.load_state_dict(wt)
+    enc = enc.to(DEV)
+    ids, mask = E.synthetic_tokens(173, 7, 128, vocab=1000, min_len=3)
+    assert enc.fuse_qkv_attention
+    a_h, a_f = enc.last_hidden_state(ids, mask).clone(), enc(ids, mask).clone()
+    enc.fuse_qkv_attention = False
+    b_h, b_f = enc.last_hidden_state(ids, mask).clone(), enc(ids, mask).clone()
+    assert torch.equal(a_h, b_h) and torch.equal(a_f, b_f)
+    assert (a_f.cpu() - E.text_features(wt, ids, mask)).abs().max().item() <= 4e-3
+
+
 @pytest.mark.parametrize("fold", [True, False])
 def test_unpadded_text_encoder_is_bit_identical_for_prefix_masks(fold):
     """BertTextEncoder(..., unpad=True) computes only the tokens the padding mask keeps (packed rows, per-sequence

@@ -123,6 +123,7 @@ def _declare_encoders(lib: C.CDLL) -> None:
         "ufnd_gemm_bf16_ex": [P] * 6 + [I] * 10 + [P],
         "ufnd_layernorm": [P, I, P, P, P, P, I, I, F, P],
         "ufnd_attention_bf16": [P, P, P, I, I, I, P],
+        "ufnd_qkv_attention_bf16": [P, P, P, P, P, I, I, I, I, I, C.POINTER(GemmLn), P],
         "ufnd_bert_embed": [P] * 8 + [I, I, I, I, F, P],
         "ufnd_masked_meanpool_l2": [P, P, P, I, I, I, P],
         "ufnd_bert_embed_packed": [P] * 9 + [I, I, I, I, F, P],

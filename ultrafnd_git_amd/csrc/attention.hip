@@ -18,6 +18,10 @@
 // degenerates to a uniform average, not NaN); keys beyond L contribute exactly zero.
 #include "common.hpp"
 
+// No implicit contraction: the fused projection + attention kernel (gemm_bf16_kernel.hpp, ATT) repeats this kernel's
+// arithmetic operation for operation and must produce the same bits; fused multiply-adds are spelled out.
+#pragma clang fp contract(off)
+
 namespace {
 
 constexpr int QB = 128;          // queries per workgroup
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const __bf16* qkv, const
           lsum += p;
           pf[kt >> 1][qt][(kt & 1) * 4 + r] = (__bf16)p;
         }
-      l_run[qt] = l_run[qt] * alpha + lsum;
+      l_run[qt] = __builtin_fmaf(l_run[qt], alpha, lsum);
       m_run[qt] = m_new;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) o[dt][qt] *= alpha;

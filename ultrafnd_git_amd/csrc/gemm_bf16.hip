@@ -97,6 +97,35 @@ extern "C" int ufnd_gemm_bf16_ln(const void* A, const void* W, const float* bias
   return UFND_OK;
 }
 
+// BertSelfAttention of one layer in ONE launch: fused Q/K/V projection (optionally of LayerNorm(X), folded) + attention.
+extern "C" int ufnd_qkv_attention_bf16(const void* X, const void* Wqkv, const float* bqkv, const int32_t* key_mask, void* ctx,
+                                       int B, int L, int heads, int ldx, int ldw, const ufnd_gemm_ln* ln, void* stream_) {
+  UFND_REQUIRE(X && Wqkv && ctx, "qkv_attention: null operand");
+  UFND_REQUIRE(L == 128 && heads >= 2 && heads % 2 == 0 && heads <= 64 && B >= 1 && B <= 16384,
+               "qkv_attention: B=%d L=%d heads=%d (this kernel is built for 128-token samples and an even head count; "
+               "use ufnd_gemm_bf16[_ln] + ufnd_attention_bf16 otherwise)", B, L, heads);
+  const int H = heads * 64;
+  UFND_REQUIRE(ldx % 8 == 0 && ldw % 8 == 0 && ldx >= H && ldw >= H && ufnd_aligned(X, 16) && ufnd_aligned(Wqkv, 16) && ufnd_aligned(ctx, 16),
+               "qkv_attention: strides must be multiples of 8 and pointers 16-B aligned");
+  UFND_REQUIRE(!bqkv || ufnd_aligned(bqkv, 16), "qkv_attention: bias alignment");
+  GemmArgs a{(const __bf16*)X, (const __bf16*)Wqkv, bqkv, nullptr, nullptr, nullptr, B * L, 3 * H, H, ldx, ldw, 0, 0, 0, UFND_ACT_NONE, 0, 0, nullptr};
+  if (ln && ln->a_stats) {
+    UFND_REQUIRE(ln->colsum && ufnd_aligned(ln->colsum, 16) && ufnd_aligned(ln->a_stats, 16), "qkv_attention: colsum / a_stats alignment");
+    UFND_REQUIRE(ln->a_parts >= 2 && ln->a_parts <= 24 && ln->a_parts % 2 == 0 && ln->width > 0, "qkv_attention: a_parts=%d width=%d", ln->a_parts, ln->width);
+    a.a_stats = ln->a_stats; a.colsum = ln->colsum; a.a_parts = ln->a_parts; a.a_eps = ln->a_eps;
+    a.inv_h = 1.0f / (float)ln->width;
+  }
+  a.att_mask = key_mask;
+  a.att_ctx = (__bf16*)ctx;
+  a.att_h = H;
+  a.att_scale_log2e = 0.125f * 1.44269504088896340736f;      // 1 / sqrt(64) * log2(e)
+  a.m_tiles = B;
+  a.n_tiles = heads / 2;
+  hipLaunchKernelGGL((gemm_bf16_kernel<128, 384, 2, 4, 3, 2, 16, 0, 0, 1, 1>), dim3(a.m_tiles * a.n_tiles), dim3(512), 0, (hipStream_t)stream_, a);
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}
+
 extern "C" int ufnd_gemm_bf16(const void* A, const void* W, const float* bias, const float* residual, void* out_bf16,
                               float* out_f32, int M, int N, int K, int lda, int ldw, int ldr, int ldo, int ldf, int act,
                               void* stream_) {

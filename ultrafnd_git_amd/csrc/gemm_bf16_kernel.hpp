@@ -51,6 +51,11 @@ struct GemmArgs {
   float* out_stats;      // (M, N / 32, 2): partial {sum, sumsq} of the fp32 output rows, one per aligned 32 columns
   int a_parts, r_parts;
   float a_eps, r_eps, inv_h;   // inv_h = 1 / (row width the statistics are over)
+  // fused attention (ATT kernels only): the tile is one sample's Q | K | V of TWO heads; see the ATT notes at the kernel
+  const int32_t* att_mask;   // (M) key mask, 1 = attend (NULL: every key)
+  __bf16* att_ctx;           // (M, att_h) attention output
+  int att_h;                 // heads * 64 (= rows of each of the three stacked weight blocks)
+  float att_scale_log2e;     // 1 / sqrt(64) * log2(e)
 };
 
 __device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst) {
@@ -91,9 +96,19 @@ template <int V> struct IntC { static constexpr int value = V; };
 //          instructions per K-step, so the SIMD's vector issue is held half as long).
 // LNX = 1: the LayerNorm-aware epilogue (row statistics in, folded normalisation, residual through a
 //          LayerNorm, row statistics out) -- see ufnd_gemm_bf16_ln.
-template <int BM, int BN, int WM, int WN, int STA, int STB, int MI, int ABL = 0, int DBG = 0, int LNX = 0>
+// ATT = 1 (BM = 128, BN = 384, MI = 16, LNX = 1): the fused-QKV projection of ONE sample (its 128 tokens are the tile's
+//          rows) for TWO heads, followed by their attention, in one workgroup.  Tile column c is column
+//          (c / 128) * att_h + 128 * pair + c % 128 of the stacked projection, i.e. [q_h q_h' | k_h k_h' | v_h v_h'] for
+//          the head pair (h, h') = (2 pair, 2 pair + 1); grid = samples x heads / 2.  The epilogue rounds the projection
+//          to bf16 exactly as the stand-alone GEMM does, but into LDS images (swizzled like attention.hip's), and the
+//          workgroup then runs attention.hip's per-wave schedule on them (wave w: head w / 4, queries 32 (w % 4) ..):
+//          S^T = K Q^T, online softmax over two 64-key blocks, O^T = V^T P^T.  Same operations in the same order as
+//          ufnd_gemm_bf16[_ln] + ufnd_attention_bf16: bit-identical ctx, without the (tokens, 3H) round trip through
+//          HBM, the second launch and its three dependent memory round trips.
+template <int BM, int BN, int WM, int WN, int STA, int STB, int MI, int ABL = 0, int DBG = 0, int LNX = 0, int ATT = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs a) {
   static_assert(MI == 16 || MI == 32, "MFMA shape");
+  static_assert(!ATT || (BM == 128 && BN == 384 && MI == 16 && WM * WN == 8 && LNX == 1), "fused attention tile");
   using acc_t = typename std::conditional<MI == 16, f32x4, f32x16>::type;
   constexpr int AR = MI * MI / 64;               // accumulator registers per MFMA tile
   constexpr int KQ = MI == 16 ? 1 : 2;           // MFMA k-steps per k-half (32 k)
@@ -111,7 +126,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
   constexpr int CP = TN + 4;                     // fp32 C-staging pitch (floats), MI rows per wave
   constexpr int CBYTES = NW * MI * CP * 4;
   constexpr int RING = STA * ASLOT + STB * BSLOT;
-  constexpr int STAT_OFF = (RING > CBYTES) ? RING : CBYTES;           // LNX: {mean, rstd} per tile row, behind the ring
+  // ATT: six 16-KiB images (Q, K, V of two heads; 128 tokens x 128 B) + 128 key biases, behind the C staging patches
+  // (they overlay the operand ring, which is dead by then)
+  constexpr int ATT_OFF = (CBYTES + 1023) & ~1023;
+  constexpr int ATT_END = ATT ? ATT_OFF + 6 * 16384 + 512 : 0;
+  constexpr int STAT_OFF0 = (RING > CBYTES) ? RING : CBYTES;
+  constexpr int STAT_OFF = STAT_OFF0 > ATT_END ? STAT_OFF0 : ATT_END;  // LNX: {mean, rstd} per tile row, behind the ring (and the images)
   constexpr int SMEM = STAT_OFF + (LNX ? BM * 8 : 0);
   static_assert(SMEM <= 160 * 1024, "LDS budget");
   static_assert(APIECES % NW == 0 && TM % MI == 0 && TN % MI == 0, "tile split");
@@ -171,6 +191,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
       const int c = ppos ^ ((r >> 1) & 7);
       int gr = n0 + r;
       gr = gr < a.N ? gr : a.N - 1;
+      if constexpr (ATT) gr = (r >> 7) * a.att_h + (bid % a.n_tiles) * 128 + (r & 127);     // [q | k | v] rows of this head pair
       dma16(a.W + (size_t)gr * a.ldw + k0 + c * 8, buf + p * 1024);
     }
   };
@@ -206,6 +227,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
           asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sv[gi][u]) : "v"(base + (q < nq ? q : 0)) : "memory");
         }
     }
+  }
+  int att_mk = 1;
+  if constexpr (ATT) {      // this sample's key mask: requested now, used after the K loop (older than every DMA piece)
+    if (a.att_mask && threadIdx.x < BM) att_mk = a.att_mask[m0 + threadIdx.x];
   }
   // prologue: every ring slot is filled (W(s) before A(s), step by step, so that a counted vmcnt
   // separates "steps <= t+1" from the later ones)
@@ -397,9 +422,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
   float bj[NT], csj[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) { bj[j] = 0.f; csj[j] = 0.f; }
+  // global column of tile column c
+  auto gcol = [&](int c) { return ATT ? (c >> 7) * a.att_h + (bid % a.n_tiles) * 128 + (c & 127) : n0 + c; };
   if (a.bias) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) bj[j] = a.bias[n0 + wn * TN + j * MI + fr];
+    for (int j = 0; j < NT; ++j) bj[j] = a.bias[gcol(wn * TN + j * MI + fr)];
   }
   bool fold = false, rln = false;
   if constexpr (LNX) {
@@ -407,7 +434,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     rln = a.r_stats != nullptr;
     if (fold) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) csj[j] = a.colsum[n0 + wn * TN + j * MI + fr];
+      for (int j = 0; j < NT; ++j) csj[j] = a.colsum[gcol(wn * TN + j * MI + fr)];
     }
   }
   float* cst = reinterpret_cast<float*>(smem) + wave * MI * CP;
@@ -509,6 +536,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
             }
           }
         }
+        if constexpr (ATT) {        // bf16 rounding of the projection (as the stand-alone GEMM stores it) into the LDS image of
+          const int ct = wn * TN + cl;                     // its (q|k|v, head): 128-B rows, 16-B chunks swizzled as attention.hip reads them
+          const int trow = wm * TM + i * MI + rr, img = ct >> 6, ch = (ct & 63) >> 3;
+          bf16x8 o;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) o[q] = (__bf16)v[q];
+          const int sw = img >= 4 ? (ch ^ (((trow >> 1) & 3) << 1)) : (ch ^ ((trow >> 1) & 7));      // V images: the transposed-read swizzle
+          *reinterpret_cast<bf16x8*>(smem + ATT_OFF + img * 16384 + trow * 128 + (sw << 4)) = o;
+          continue;
+        }
         if (!live) continue;
         if (a.out_f32) {
           float* op = a.out_f32 + (size_t)row * a.ldf + col;
@@ -539,6 +576,114 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     if (a.act == UFND_ACT_GELU) epilogue(IntC<UFND_ACT_GELU>{}, IntC<0>{});
     else if (a.act == UFND_ACT_QUICK_GELU) epilogue(IntC<UFND_ACT_QUICK_GELU>{}, IntC<0>{});
     else epilogue(IntC<UFND_ACT_NONE>{}, IntC<0>{});
+  }
+  if constexpr (ATT) {
+    // ---- attention of the tile's two heads on the LDS images (attention.hip's per-wave schedule, L = 128 = two key blocks)
+    constexpr float NEG_MASK = -3.0e38f;
+    float* kbias = reinterpret_cast<float*>(smem + ATT_OFF + 6 * 16384);
+    if (threadIdx.x < BM) kbias[threadIdx.x] = att_mk != 0 ? 0.0f : NEG_MASK;
+    __syncthreads();
+    const int hh = wave >> 2, wq = wave & 3, g4 = lane >> 4, f16 = lane & 15;
+    const char* qimg = smem + ATT_OFF + hh * 16384;
+    const char* kimg = smem + ATT_OFF + (2 + hh) * 16384;
+    const char* vimg = smem + ATT_OFF + (4 + hh) * 16384;
+    bf16x8 qf[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const int q = wq * 32 + qt * 16 + f16;
+      qf[qt][0] = lds_frag(qimg, q, g4);
+      qf[qt][1] = lds_frag(qimg, q, g4 + 4);
+    }
+    f32x4 o[4][2];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) o[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    constexpr int KB = 64, KT = KB / 16;
+#pragma unroll
+    for (int kb0 = 0; kb0 < BM; kb0 += KB) {
+      const char* ks = kimg + kb0 * 128;
+      const char* vs = vimg + kb0 * 128;
+      f32x4 sc[KT][2];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) sc[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          const bf16x8 kf = lds_frag(ks, kt * 16 + f16, g4 + 4 * kk);
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt) sc[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][kk], sc[kt][qt], 0, 0, 0);
+        }
+      bf16x8 pf[KT / 2][2];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          const f32x4 kbv = *reinterpret_cast<const f32x4*>(kbias + kb0 + kt * 16 + 4 * g4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = (kbv[r] == 0.0f) ? sc[kt][qt][r] * a.att_scale_log2e : kbv[r];
+            sc[kt][qt][r] = v;
+            mx = fmaxf(mx, v);
+          }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run[qt], mx);
+        const float alpha = exp2f(m_run[qt] - m_new);
+        float lsum = 0.0f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = exp2f(sc[kt][qt][r] - m_new);
+            lsum += pv;
+            pf[kt >> 1][qt][(kt & 1) * 4 + r] = (__bf16)pv;
+          }
+        l_run[qt] = __builtin_fmaf(l_run[qt], alpha, lsum);
+        m_run[qt] = m_new;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt][qt] *= alpha;
+      }
+#pragma unroll
+      for (int ksd = 0; ksd < KT / 2; ++ksd) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const int qq = f16 >> 2, pp = f16 & 3;
+          const int key0 = 32 * ksd + 4 * g4 + qq;
+          const int ch = 2 * dt + (pp >> 1);
+          const int off0 = key0 * 128 + ((ch ^ (((key0 >> 1) & 3) << 1)) << 4) + 8 * (pp & 1);
+          const int key1 = key0 + 16;
+          const int off1 = key1 * 128 + ((ch ^ (((key1 >> 1) & 3) << 1)) << 4) + 8 * (pp & 1);
+          const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vs + off0));
+          const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vs + off1));
+          union { s16x4 s2[2]; bf16x8 v; } u;
+          u.s2[0] = t0;
+          u.s2[1] = t1;
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt) o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, pf[ksd][qt], o[dt][qt], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float l = l_run[qt];
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+      const float inv = 1.0f / l;
+      const int q = wq * 32 + qt * 16 + f16;
+      __bf16* dst = a.att_ctx + (size_t)(m0 + q) * a.att_h + ((bid % a.n_tiles) * 2 + hh) * 64 + 4 * g4;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        bf16x4 ov = {(__bf16)(o[dt][qt][0] * inv), (__bf16)(o[dt][qt][1] * inv), (__bf16)(o[dt][qt][2] * inv), (__bf16)(o[dt][qt][3] * inv)};
+        *reinterpret_cast<bf16x4*>(dst + dt * 16) = ov;
+      }
+    }
   }
   if constexpr (DBG) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

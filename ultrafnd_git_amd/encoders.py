@@ -182,6 +182,22 @@ class _EncoderBase(nn.Module):
         L.check(L.lib().ufnd_layernorm(x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), L.ptr(out_bf16),
                                        L.ptr(out_f32), M, H, eps, L.stream_ptr(x.device)), "ufnd_layernorm")
 
+    def _qkv_attn(self, A, W, bias, mask_i32, ctx, B, Lq, heads, a_stats=None, colsum=None, eps=1e-5):
+        """ufnd_qkv_attention_bf16: fused Q/K/V projection (+ folded LayerNorm of A) + attention, one launch per layer."""
+        import ctypes
+        ln = None
+        if a_stats is not None:
+            ln = L.GemmLn()
+            ln.a_stats, ln.colsum, ln.a_parts, ln.a_eps, ln.r_eps, ln.width = a_stats.data_ptr(), colsum.data_ptr(), a_stats.shape[1], eps, eps, self.hidden
+        L.check(L.lib().ufnd_qkv_attention_bf16(A.data_ptr(), W.data_ptr(), L.ptr(bias), L.ptr(mask_i32), ctx.data_ptr(), B, Lq, heads,
+                                                A.stride(0), W.stride(0), ctypes.byref(ln) if ln is not None else None,
+                                                L.stream_ptr(A.device)), "ufnd_qkv_attention_bf16")
+        if self.guarded and a_stats is not None:
+            if self._guard is None or self._guard.device != A.device:
+                self._guard = torch.zeros(1, dtype=torch.float32, device=A.device)
+            L.check(L.lib().ufnd_ln_fold_guard(a_stats.data_ptr(), A.shape[0], a_stats.shape[1], self.hidden, eps, self._guard.data_ptr(),
+                                               L.stream_ptr(A.device)), "ufnd_ln_fold_guard")
+
     def _attn(self, qkv, mask_i32, ctx, B, Lq, heads):
         L.check(L.lib().ufnd_attention_bf16(qkv.data_ptr(), L.ptr(mask_i32), ctx.data_ptr(), B, Lq, heads,
                                             L.stream_ptr(qkv.device)), "ufnd_attention_bf16")
@@ -194,6 +210,9 @@ class BertTextEncoder(_EncoderBase):
                  fold_ln: bool = True):
         super().__init__()
         self.fold_ln = fold_ln
+        # 128-token samples: Q/K/V projection + attention of a layer as ONE launch (ufnd_qkv_attention_bf16); bit-identical
+        # to the two-launch form, which every other length uses
+        self.fuse_qkv_attention = True
         if hidden != heads * 64:
             raise ValueError("head_dim must be 64 (hidden == heads * 64)")
         self.layers, self.hidden, self.heads, self.inter, self.vocab, self.eps = layers, hidden, heads, intermediate, vocab_size, eps
@@ -284,37 +303,48 @@ class BertTextEncoder(_EncoderBase):
                                         w["embeddings.LayerNorm.weight"].data_ptr(), w["embeddings.LayerNorm.bias"].data_ptr(),
                                         b["xb"].data_ptr(), b["xf"].data_ptr(), B, Lq, H, self.vocab, self.eps,
                                         L.stream_ptr(dev)), "ufnd_bert_embed")
-        self._layers(p, b, M, lambda qkv, ctx: self._attn(qkv, mask, ctx, B, Lq, self.heads))
+        fused = (B, Lq, mask) if (self.fuse_qkv_attention and Lq == 128 and self.heads % 2 == 0) else None
+        self._layers(p, b, M, lambda qkv, ctx: self._attn(qkv, mask, ctx, B, Lq, self.heads), fused)
         return b["xf"].view(B, Lq, H)
 
-    def _layers(self, p, b, M, attn) -> None:
+    def _layers(self, p, b, M, attn, fused=None) -> None:
         """The encoder layers over the first M rows of the work buffers; attn(qkv, ctx) runs the attention (padded
         batch or packed sequences).  Leaves last_hidden_state in b["xf"] (and its bf16 rounding in b["xb"])."""
         H = self.hidden
         v = {k: (x[:M] if torch.is_tensor(x) and x.dim() >= 2 and x.shape[0] >= M and k != "feat" else x) for k, x in b.items()}
         if "st1" in b:
-            return self._layers_folded(p, v, M, attn)
+            return self._layers_folded(p, v, M, attn, fused)
         for ly in p["layers"]:
-            self._gemm(v["xb"], ly["wqkv"], ly["bqkv"], out_bf16=v["qkv"], which="qkv")
-            attn(v["qkv"], v["ctx"])
+            if fused is not None:
+                self._qkv_attn(v["xb"], ly["wqkv"], ly["bqkv"], fused[2], v["ctx"], fused[0], fused[1], self.heads)
+            else:
+                self._gemm(v["xb"], ly["wqkv"], ly["bqkv"], out_bf16=v["qkv"], which="qkv")
+                attn(v["qkv"], v["ctx"])
             self._gemm(v["ctx"], ly["wo"], ly["bo"], out_f32=v["y"], residual=v["xf"], which="out")
             self._ln(v["y"], H, ly["g1"], ly["b1"], v["x1b"], v["x1f"], M, H, self.eps)
             self._gemm(v["x1b"], ly["w1"], ly["bi"], out_bf16=v["h"], act=ACT_GELU, which="ffn1")
             self._gemm(v["h"], ly["w2"], ly["b2"], out_f32=v["y"], residual=v["x1f"], which="ffn2")
             self._ln(v["y"], H, ly["g2"], ly["b2n"], v["xb"], v["xf"], M, H, self.eps)
 
-    def _layers_folded(self, p, b, M, attn) -> None:
+    def _layers_folded(self, p, b, M, attn, fused=None) -> None:
         """The layers without a LayerNorm kernel between Linears (module docstring).  y1 / y2 are the
         PRE-LayerNorm sums of the attention and the feed-forward halves (fp32 + bf16 + row statistics)."""
         H, eps = self.hidden, self.eps
         y1, y2 = b["y"], b["y2"]
         prev = None
         for ly in p["layers"]:
-            if prev is None:      # layer 0 consumes the embeddings' own (materialised) LayerNorm
+            if fused is not None:
+                if prev is None:
+                    self._qkv_attn(b["xb"], ly["wqkv"], ly["bqkv"], fused[2], b["ctx"], fused[0], fused[1], self.heads)
+                else:
+                    self._qkv_attn(b["y2b"], ly["wqkvf"], ly["bqkvf"], fused[2], b["ctx"], fused[0], fused[1], self.heads,
+                                   a_stats=b["st2"], colsum=ly["csqkv"], eps=eps)
+            elif prev is None:      # layer 0 consumes the embeddings' own (materialised) LayerNorm
                 self._gemm(b["xb"], ly["wqkv"], ly["bqkv"], out_bf16=b["qkv"], which="qkv")
             else:
                 self._gemm_ln(b["y2b"], ly["wqkvf"], ly["bqkvf"], out_bf16=b["qkv"], a_stats=b["st2"], colsum=ly["csqkv"], eps=eps, which="qkv")
-            attn(b["qkv"], b["ctx"])
+            if fused is None:
+                attn(b["qkv"], b["ctx"])
             if prev is None:
                 self._gemm_ln(b["ctx"], ly["wo"], ly["bo"], out_f32=y1, out_bf16=b["y1b"], residual=b["xf"], out_stats=b["st1"], eps=eps, which="out")
             else:

@@ -622,7 +622,7 @@ class ForensicTrainer:
         originals = []
         passes: List[Tuple[int, int]] = []
         for enc in (self.text_encoder, self.visual_encoder):
-            for name in ("_gemm", "_gemm_ln"):       # the plain and the LayerNorm-aware entry: the same kernel family
+            for name in ("_gemm", "_gemm_ln", "_qkv_attn"):       # plain, LayerNorm-aware and fused-attention entries: one kernel family
                 orig = getattr(enc, name)
 
                 def timed(A, W, *a, _orig=orig, **kw):
