@@ -102,10 +102,27 @@ __global__ __launch_bounds__(256) void meanpool_kernel(const float* hidden, cons
   const int b = blockIdx.y, col = blockIdx.x * 256 + 4 * (threadIdx.x & 63), grp = threadIdx.x >> 6, lane = threadIdx.x & 63;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   float cnt = 0.0f;
-  for (int l = grp; l < L; l += 4) {
-    if (mask[(size_t)b * L + l] != 0) {
-      acc += ld4(hidden + ((size_t)b * L + l) * H + col);
-      cnt += 1.0f;
+  // eight tokens of the group per pass: their mask words and rows are requested together (a mask load -> branch -> row
+  // load chain per token made this kernel 27 us for 12.6 MB); rows are added in token order, only where the mask keeps them
+  for (int l0 = grp; l0 < L; l0 += 32) {
+    int mk[8];
+    f32x4 x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int l = l0 + 4 * u;
+      mk[u] = l < L ? mask[(size_t)b * L + l] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int l = l0 + 4 * u < L ? l0 + 4 * u : L - 1;
+      x[u] = ld4(hidden + ((size_t)b * L + l) * H + col);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (mk[u] != 0) {
+        acc += x[u];
+        cnt += 1.0f;
+      }
     }
   }
   part[grp][lane] = acc;
