@@ -202,6 +202,12 @@ int ufnd_grad_norm(const float* grad, size_t n, float* partials, ufnd_step_state
 int ufnd_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
                     const ufnd_step_state* state, void* stream);
 int ufnd_step_advance(ufnd_step_state* state, void* stream);
+/* The three calls above (four launches) as ONE call of two launches, for a single arena: the sum of squares (its first
+ * block also advances state->step), then AdamW, in which every block re-derives the norm, the clip coefficient and the
+ * bias corrections from the partials.  Same arithmetic in the same order: parameters, moments and the published scalars
+ * are bit-identical to the three-call form. */
+int ufnd_clip_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float* partials,
+                         ufnd_step_state* state, void* stream);
 
 /* ====================================================================================
  * Tier B -- the frozen, forward-only encoders that produce `text` and `visual`

@@ -154,3 +154,26 @@ def test_indexed_batches_gather_in_one_launch_and_equal_collated_ones(tmp_path):
         rb = b.train_step(b.train_loader.dataset.gather(sel))
         assert la == float(rb["loss"]) and torch.equal(ra["logits"], rb["logits"])
     assert torch.equal(a.arena.data, b.arena.data)
+
+
+def test_two_launch_optimizer_is_bit_identical_to_the_four_launch_form(tmp_path):
+    """ufnd_clip_adamw_step (sum of squares + step counter; norm / clip / bias corrections re-derived in every AdamW block)
+    against ufnd_grad_norm + ufnd_adamw_step + ufnd_step_advance: parameters, both moments and the published scalars,
+    three steps with the clip active (max_norm 0.05)."""
+    res = []
+    for fused in (True, False):
+        torch.manual_seed(11)
+        tr = _trainer(tmp_path, 2, False, grad_clip=0.05)
+        tr.optim.fused = fused
+        tr.fusion.train(); tr.clf.train()
+        it = iter(tr.train_loader)
+        scal = []
+        for _ in range(3):
+            tr.train_step(next(it))
+            st = tr.optim.state.read()
+            scal.append((int(st.step), float(st.grad_norm), float(st.clip_coef), float(st.bc1), float(st.bc2_sqrt)))
+        res.append((tr.arena.data.clone(), tr.arena.exp_avg.clone(), tr.arena.exp_avg_sq.clone(), scal))
+    assert res[0][3] == res[1][3] and [s[0] for s in res[0][3]] == [1, 2, 3]
+    assert any(s[2] < 1.0 for s in res[0][3])                 # the clip really was active
+    for a, b in zip(res[0][:3], res[1][:3]):
+        assert torch.equal(a, b)

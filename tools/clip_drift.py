@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""How far does the HIP trainer drift from the reference's trajectory when the gradient clip is active on most steps?
+(GPU box; VERDICT r1 weak #7.)
+
+The HIP grad-norm equals the float64 norm of the gradients to 5e-5, while the reference's fp32 `clip_grad_norm_` on CPU reads
+2.5e-4 .. 6e-4 LOW on the 8.4 M-element fuse_mlp.0.weight gradient (torch.linalg.vector_norm's fp32 accumulation), so the two
+clip coefficients differ by that much on every clipped step.  This runs `steps` optimizer steps on a clipping-heavy synthetic
+stream (small batches of un-normalised features: the norm stays far above max_norm = 5) three ways from the same weights --
+  hip    ForensicTrainer.train_step (this package, dropout off),
+  ref    the oracle's restatement of the reference step (fp32 clip_grad_norm_ exactly as torch computes it on CPU),
+  ref64  the same with the total norm accumulated in float64 (what the HIP norm is) --
+and reports, every `every` steps, the max-abs difference of the logits on a fixed held-out batch.  hip vs ref64 isolates
+everything that is NOT the norm arithmetic (fp32 summation order inside the kernels, amplified by the training dynamics);
+ref vs ref64 is the effect of the norm arithmetic alone.
+usage: clip_drift.py [steps=200] [B=4] [every=20] [scale=4.0]"""
+import json
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch
+
+from oracle import tier_a as O
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+every = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+scale = float(sys.argv[4]) if len(sys.argv) > 4 else 4.0
+DEV = "cuda"
+KEYS = ("text_features", "audio_features", "visual_features", "temporal_features", "gnn_feat", "aux", "label")
+
+
+def batches(n, seed):
+    out = []
+    for i in range(n):
+        b = O.seeded_batch(seed + i, B)
+        for k in KEYS[:5]:
+            b[k] = b[k] * scale              # un-normalised features: gradient norms far above the clip threshold
+        out.append(b)
+    return out
+
+
+def clip64_(grads, max_norm):
+    gs = [g for g in grads.values() if g is not None]
+    total = torch.sqrt(sum(g.double().pow(2).sum() for g in gs)).float()
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    for g in gs:
+        g.mul_(coef)
+    return float(total)
+
+
+def main():
+    from ultrafnd_git_amd.trainer import ForensicTrainer, TrainConfig, synthetic_cache
+    stream = batches(steps, 1000)
+    held = O.seeded_batch(7, 32)
+    fus0, clf0 = O.seeded_params(1234)
+    clone = lambda d: {k: v.clone() for k, v in d.items()}
+    # --- the two CPU trajectories
+    traj = {}
+    for tag, clip in (("ref", O.clip_grads_), ("ref64", clip64_)):
+        fus, clf, opt = clone(fus0), clone(clf0), O.AdamWState()
+        logs, norms, clipped = [], [], 0
+        orig = O.clip_grads_
+        O.clip_grads_ = clip
+        try:
+            for i, b in enumerate(stream):
+                _, _, total = O.train_step(fus, clf, b, opt, grad_clip=5.0, train=False)
+                norms.append(total)
+                clipped += total > 5.0
+                if (i + 1) % every == 0:
+                    logs.append(O.forward_batch(fus, clf, held)["logits"].detach().clone())
+        finally:
+            O.clip_grads_ = orig
+        traj[tag] = (logs, norms, clipped)
+    # --- the HIP trajectory
+    cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir="/tmp/ufnd_clip", batch_size=B, device=DEV, use_graph=False)
+    tr = ForensicTrainer(cfg, cache=synthetic_cache(64, seed=1))
+    tr.fusion.load_state_dict(fus0); tr.clf.load_state_dict(clf0)
+    tr.fusion.dropout = tr.clf.dropout = tr.clf.node_dropout = 0.0
+    tr._step_bufs.clear()
+    hip_logs, hip_norms = [], []
+    hb = {k: v.to(DEV) for k, v in held.items()}
+    for i, b in enumerate(stream):
+        tr.fusion.train(); tr.clf.train()
+        tr.train_step({k: v.to(DEV) for k, v in b.items()})
+        hip_norms.append(float(tr.optim.state.read().grad_norm))
+        if (i + 1) % every == 0:
+            hip_logs.append(tr._forward_batch(hb, "val")["logits"].detach().cpu().clone())
+    rows = []
+    for j in range(len(hip_logs)):
+        rows.append({"step": (j + 1) * every,
+                     "hip_vs_ref": (hip_logs[j] - traj["ref"][0][j]).abs().max().item(),
+                     "hip_vs_ref64": (hip_logs[j] - traj["ref64"][0][j]).abs().max().item(),
+                     "ref_vs_ref64": (traj["ref"][0][j] - traj["ref64"][0][j]).abs().max().item(),
+                     "logit_scale": traj["ref"][0][j].abs().max().item()})
+    rel = [abs(a - b) / b for a, b in zip(traj["ref"][1], traj["ref64"][1])]
+    relh = [abs(a - b) / b for a, b in zip(hip_norms, traj["ref64"][1])]
+    print(json.dumps({"steps": steps, "B": B, "feature_scale": scale, "clipped_steps": int(traj["ref"][2]),
+                      "norm_first_last": [traj["ref"][1][0], traj["ref"][1][-1]],
+                      "fp32_norm_rel_error_first10_mean": sum(rel[:10]) / 10, "hip_norm_rel_error_first10_mean": sum(relh[:10]) / 10,
+                      "rows": rows}, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -108,6 +108,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.ufnd_grad_norm.argtypes = [P, S, P, P, P]
     lib.ufnd_adamw_step.argtypes = [P, P, P, P, S, P, P]
     lib.ufnd_step_advance.argtypes = [P, P]
+    lib.ufnd_clip_adamw_step.argtypes = [P, P, P, P, S, P, P, P]
+    lib.ufnd_clip_adamw_step.restype = I
     for name in ("ufnd_fusion_forward", "ufnd_fusion_backward", "ufnd_classifier_forward", "ufnd_classifier_backward",
                  "ufnd_softmax_ce", "ufnd_grad_norm", "ufnd_adamw_step", "ufnd_step_advance"):
         getattr(lib, name).restype = I

@@ -85,15 +85,29 @@ __device__ __forceinline__ float quad_xor2(float v) {       // lane ^ 2: quad_pe
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
 }
 
+// Wave-wide reductions by DPP (no LDS round trips: a __shfl_xor butterfly is six dependent ds_bpermute, ~100 cycles
+// each -- the row kernels of the head spend most of their time in them).  Rows of 16 lanes reduce by quad_perm /
+// row_half_mirror / row_mirror, the four rows combine by row_bcast15 / row_bcast31 (wave64), the total lands in lane 63
+// and is broadcast through an SGPR.  Every lane returns the same value; the association order is fixed.
+#define UFND_DPP(v, old, ctrl, rmask) \
+  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(old)), __builtin_bit_cast(int, (float)(v)), ctrl, rmask, 0xF, false))
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += UFND_DPP(v, 0.0f, 0xB1, 0xF);     // quad_perm [1,0,3,2]
+  v += UFND_DPP(v, 0.0f, 0x4E, 0xF);     // quad_perm [2,3,0,1]
+  v += UFND_DPP(v, 0.0f, 0x141, 0xF);    // row_half_mirror
+  v += UFND_DPP(v, 0.0f, 0x140, 0xF);    // row_mirror: every lane holds its row's sum
+  v += UFND_DPP(v, 0.0f, 0x142, 0xA);    // row_bcast15 into rows 1 and 3
+  v += UFND_DPP(v, 0.0f, 0x143, 0xC);    // row_bcast31 into rows 2 and 3: lane 63 holds the total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, UFND_DPP(v, v, 0xB1, 0xF));
+  v = fmaxf(v, UFND_DPP(v, v, 0x4E, 0xF));
+  v = fmaxf(v, UFND_DPP(v, v, 0x141, 0xF));
+  v = fmaxf(v, UFND_DPP(v, v, 0x140, 0xF));
+  v = fmaxf(v, UFND_DPP(v, v, 0x142, 0xA));     // (lanes outside the row mask keep `old` = their own value)
+  v = fmaxf(v, UFND_DPP(v, v, 0x143, 0xC));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // ------------------------------------------------------------------ counter-based dropout RNG

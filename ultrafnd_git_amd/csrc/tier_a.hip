@@ -114,13 +114,12 @@ struct EvPtrs {
 struct EvGrads {
   float *w0[3], *b0[3], *w2[3], *b2[3];
 };
+// ---------------------------------------------------------------- co-attention + pairwise -> CAT
+// cross_modal_transformer.py:44-54 and :172-178
+// evidence scalars + gates of a row (shared by the stand-alone kernel above and the fused one below): the same operation
+// sequence, so both give the same bits
 template <int NI>
-__global__ __launch_bounds__(256) void evidence_gate_kernel(const float* cat, int B, int H, EvPtrs ev, float* evid,
-                                                            float* gate, float* forensic) {
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + w;
-  if (row >= B) return;
-  const float* c = cat + (size_t)row * 16 * H;
+__device__ __forceinline__ void evidence_row(const float* c, int H, int lane, const EvPtrs& ev, float (&e3)[3], float (&g)[3]) {
   float tt = 0, vv = 0, uu = 0, tv = 0, tu = 0, ta = 0;
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
@@ -134,8 +133,8 @@ __global__ __launch_bounds__(256) void evidence_gate_kernel(const float* cat, in
   const float conf = 1.0f - 0.5f * (fminf(fmaxf(tv / (nt * nv), -1.0f), 1.0f) + 1.0f);
   const float delay = 1.0f - 0.5f * (fminf(fmaxf(tu / (nt * nu), -1.0f), 1.0f) + 1.0f);
   const float emo = tanhf(ta / (float)H);
+  e3[0] = conf; e3[1] = emo; e3[2] = delay;
   const float e[3][3] = {{conf, emo, 0.f}, {emo, 0.f, 0.f}, {delay, 0.f, 0.f}};
-  float g[3];
 #pragma unroll
   for (int b = 0; b < 3; ++b) {
     float o = 0.0f;
@@ -148,25 +147,34 @@ __global__ __launch_bounds__(256) void evidence_gate_kernel(const float* cat, in
     }
     g[b] = sigmoid_f(wave_sum(o) + ev.b2[b][0]);
   }
-  if (lane == 0) {
-    st4(evid + (size_t)row * 4, f32x4{conf, emo, delay, 0.f});
-    st4(gate + (size_t)row * 4, f32x4{g[0], g[1], g[2], 0.f});
-    forensic[row] = emo;              // emotion_intensity
-    forensic[B + row] = conf;         // semantic_conflict
-    forensic[2 * B + row] = delay;    // temporal_delay
-  }
 }
 
-// ---------------------------------------------------------------- co-attention + pairwise -> CAT
-// cross_modal_transformer.py:44-54 and :172-178
-template <int NI>
-__global__ __launch_bounds__(256) void coattn_pairs_kernel(float* cat, const float* qkv, const float* gate, int B,
-                                                           int H, float* s_out) {
+// EVID = 1: the evidence scalars / gates of the row are computed here too (one launch instead of evidence_gate_kernel +
+// this one: the row's t, v, u are read by both anyway) and written to evid / gate_io / forensic.
+template <int NI, int EVID = 0>
+__global__ __launch_bounds__(256) void coattn_pairs_kernel(float* cat, const float* qkv, float* gate_io, int B,
+                                                           int H, float* s_out, EvPtrs ev, float* evid, float* forensic) {
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + w;
   if (row >= B) return;
   float* c = cat + (size_t)row * 16 * H;
   const float* q = qkv + (size_t)row * 9 * H;
+  const float* gate = gate_io;
+  f32x4 gt;
+  if constexpr (EVID) {
+    float e3[3], g3[3];
+    evidence_row<NI>(c, H, lane, ev, e3, g3);
+    gt = f32x4{g3[0], g3[1], g3[2], 0.f};
+    if (lane == 0) {
+      st4(evid + (size_t)row * 4, f32x4{e3[0], e3[1], e3[2], 0.f});
+      st4(gate_io + (size_t)row * 4, gt);
+      forensic[row] = e3[1];              // emotion_intensity
+      forensic[B + row] = e3[0];          // semantic_conflict
+      forensic[2 * B + row] = e3[2];      // temporal_delay
+    }
+  } else {
+    gt = ld4(gate + (size_t)row * 4);
+  }
   const int QI[3] = {0, 1, 4}, KI[3] = {2, 5, 7}, VI[3] = {3, 6, 8};
   const int XS[3] = {0, 0, 2}, YS[3] = {2, 1, 3};
   float dots[3] = {0.f, 0.f, 0.f};
@@ -181,7 +189,6 @@ __global__ __launch_bounds__(256) void coattn_pairs_kernel(float* cat, const flo
   const float inv = 1.0f / sqrtf((float)H);
 #pragma unroll
   for (int b = 0; b < 3; ++b) s[b] = sigmoid_f(wave_sum(dots[b]) * inv);
-  const f32x4 gt = ld4(gate + (size_t)row * 4);
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int col = 4 * lane + 256 * i;
@@ -390,20 +397,22 @@ __global__ void head2_bwd_kernel(const float* dlog, const float* Z, int B, int H
 }
 
 // ---------------------------------------------------------------- classifier pieces
-__global__ void pack_xin_kernel(const float* fused, int ldf, const float* aux, int aux_dim, float* xin, int ldx,
-                                int B, int H, int copy_fused) {
-  const int row = blockIdx.x;
-  if (row >= B) return;
-  if (copy_fused)
-    for (int c = threadIdx.x; c < H; c += blockDim.x) xin[(size_t)row * ldx + c] = fused[(size_t)row * ldf + c];
-  if (threadIdx.x < 4)
-    xin[(size_t)row * ldx + H + threadIdx.x] = (aux && (int)threadIdx.x < aux_dim) ? aux[row * aux_dim + threadIdx.x] : 0.0f;
-}
-
-// alpha[tk] = softmax(gates[tk])                        deep_truth_classifier.py:64
-__global__ __launch_bounds__(256) void alpha_kernel(const float* gates, float* alpha, int H) {
+// One launch ahead of the classifier's GEMMs.  Blocks [0, B): the input panel [fused | aux | 0] (the fused columns are
+// copied only when the fusion did not write them in place).  Blocks [B, B + trees * depth): alpha[tk] = softmax(gates[tk])
+// (deep_truth_classifier.py:64).
+__global__ __launch_bounds__(256) void clf_prep_kernel(const float* fused, int ldf, const float* aux, int aux_dim, float* xin, int ldx,
+                                                       int B, int H, int copy_fused, const float* gates, float* alpha) {
   __shared__ float sh[4];
-  const float* gp = gates + (size_t)blockIdx.x * H;
+  if ((int)blockIdx.x < B) {
+    const int row = blockIdx.x;
+    if (copy_fused)
+      for (int c = threadIdx.x; c < H; c += blockDim.x) xin[(size_t)row * ldx + c] = fused[(size_t)row * ldf + c];
+    if (threadIdx.x < 4)
+      xin[(size_t)row * ldx + H + threadIdx.x] = (aux && (int)threadIdx.x < aux_dim) ? aux[row * aux_dim + threadIdx.x] : 0.0f;
+    return;
+  }
+  const int tk = blockIdx.x - B;
+  const float* gp = gates + (size_t)tk * H;
   float mx = -INFINITY;
   for (int c = threadIdx.x; c < H; c += 256) mx = fmaxf(mx, gp[c]);
   mx = wave_max(mx);
@@ -417,7 +426,7 @@ __global__ __launch_bounds__(256) void alpha_kernel(const float* gates, float* a
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
   __syncthreads();
   s = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-  for (int c = threadIdx.x; c < H; c += 256) alpha[(size_t)blockIdx.x * H + c] = __expf(gp[c] - mx) / s;
+  for (int c = threadIdx.x; c < H; c += 256) alpha[(size_t)tk * H + c] = __expf(gp[c] - mx) / s;
 }
 
 // NODE ensemble + bypass + temperature softmax        deep_truth_classifier.py:54-74,88-90,164-170
@@ -480,7 +489,11 @@ __global__ __launch_bounds__(256) void node_head_kernel(const float* hh, const f
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const float tl = wave_sum(prob * lf[c]);
-      lg[c] += tl * dropout_mul(st, node_p, LAYER_TREE, (uint32_t)((row * trees + t) * 2 + c));
+      const float dm = dropout_mul(st, node_p, LAYER_TREE, (uint32_t)((row * trees + t) * 2 + c));
+      lg[c] += tl * dm;
+      // backward reads the multiplier back instead of re-running Philox per (row, tree, class) -- in node_param's
+      // leaf-table block that was 32 rows x 10 Philox rounds per thread, the longest chain of the whole backward
+      if (lane == 0) fs[(size_t)row * 64 + 32 + t * 2 + c] = dm;
     }
   }
   if (lane == 0) {
@@ -510,8 +523,8 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(const float* dlog, const 
   float my_df = 0.0f;
   if (lane < TK) {
     const int t = lane / depth, k = lane % depth;
-    const float d0 = dl0 / (float)trees * dropout_mul(st, node_p, LAYER_TREE, (uint32_t)((row * trees + t) * 2));
-    const float d1 = dl1 / (float)trees * dropout_mul(st, node_p, LAYER_TREE, (uint32_t)((row * trees + t) * 2 + 1));
+    const float d0 = dl0 / (float)trees * fs[(size_t)row * 64 + 32 + t * 2];          // cached dropout multipliers (node_head)
+    const float d1 = dl1 / (float)trees * fs[(size_t)row * 64 + 32 + t * 2 + 1];
     float ds = 0.0f;
     for (int l = 0; l < leaves; ++l) {
       float prod = 1.0f;
@@ -564,21 +577,26 @@ __global__ __launch_bounds__(256) void node_param_kernel(const float* df, const 
   if (blk < TK) {
     float da[4] = {0, 0, 0, 0};
     float part = 0;
-    int cnt = 0;
-    for (int c = threadIdx.x; c < H; c += 256, ++cnt) {
-      float s = 0;
+#pragma unroll
+    for (int cnt = 0; cnt < 4; ++cnt) {          // H <= 1024: at most four columns per thread (static indices: registers, not scratch)
+      const int c = threadIdx.x + 256 * cnt;
+      if (c < H) {
+        float s = 0;
 #pragma unroll 8
-      for (int r = 0; r < B; ++r) s += df[(size_t)r * 64 + blk] * hh[(size_t)r * H + c];
-      da[cnt] = s;
-      part += alpha[(size_t)blk * H + c] * s;
+        for (int r = 0; r < B; ++r) s += df[(size_t)r * 64 + blk] * hh[(size_t)r * H + c];
+        da[cnt] = s;
+        part += alpha[(size_t)blk * H + c] * s;
+      }
     }
     part = wave_sum(part);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = part;
     __syncthreads();
     const float dotv = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-    cnt = 0;
-    for (int c = threadIdx.x; c < H; c += 256, ++cnt)
-      g_gates[(size_t)blk * H + c] = alpha[(size_t)blk * H + c] * (da[cnt] - dotv);
+#pragma unroll
+    for (int cnt = 0; cnt < 4; ++cnt) {
+      const int c = threadIdx.x + 256 * cnt;
+      if (c < H) g_gates[(size_t)blk * H + c] = alpha[(size_t)blk * H + c] * (da[cnt] - dotv);
+    }
     if (threadIdx.x == 0) {
       float s = 0;
 #pragma unroll 8
@@ -611,8 +629,7 @@ __global__ __launch_bounds__(256) void node_param_kernel(const float* df, const 
           const float sk = fs[(size_t)r * 64 + t * depth + k];
           prob *= ((l >> k) & 1) ? sk : (1.0f - sk);
         }
-        s += prob * dlog[r * 2 + c] / (float)trees *
-             dropout_mul(st, node_p, LAYER_TREE, (uint32_t)((r * trees + t) * 2 + c));
+        s += prob * dlog[r * 2 + c] / (float)trees * fs[(size_t)r * 64 + 32 + t * 2 + c];
       }
       g_leaf[idx] = s;
     }
@@ -679,8 +696,8 @@ int check_dims(const ufnd_dims* d, int B) {
   UFND_REQUIRE(d, "dims is null");
   UFND_REQUIRE(d->hidden == 256 || d->hidden == 512 || d->hidden == 1024, "hidden=%d: supported 256/512/1024", d->hidden);
   UFND_REQUIRE(d->classes == 2, "classes=%d: only 2 supported", d->classes);
-  UFND_REQUIRE(d->depth >= 1 && d->depth <= 6 && d->trees >= 1 && d->trees * d->depth <= 64, "trees=%d depth=%d unsupported",
-               d->trees, d->depth);
+  UFND_REQUIRE(d->depth >= 1 && d->depth <= 6 && d->trees >= 1 && d->trees * d->depth <= 32 && d->trees <= 16, "trees=%d depth=%d unsupported",
+               d->trees, d->depth);   // (a row's 64-float slot: 32 gate activations + 2 dropout multipliers per tree)
   UFND_REQUIRE(d->aux_dim >= 0 && d->aux_dim <= 4 && d->aux_dim % 2 == 0, "aux_dim=%d: supported 0, 2, 4", d->aux_dim);
   UFND_REQUIRE(d->text_dim % 4 == 0 && d->audio_dim % 4 == 0 && d->visual_dim % 4 == 0 && d->temporal_dim % 4 == 0 &&
                    d->gnn_dim % 4 == 0, "input feature dims must be multiples of 4");
@@ -774,12 +791,7 @@ extern "C" int ufnd_fusion_forward(const ufnd_dims* d, const ufnd_fusion_params*
                      0, 0.0f, 0, 1};
     TRY(launch_nt(pr, 5, state, stream));
   }
-  // 2. evidence scalars and the three evidence gates                                  (:153-164,48)
-  EvPtrs ev;
-  for (int b = 0; b < 3; ++b) { ev.w0[b] = p->ev0_w[b]; ev.b0[b] = p->ev0_b[b]; ev.w2[b] = p->ev2_w[b]; ev.b2[b] = p->ev2_b[b]; }
-  NI_DISPATCH(H, evidence_gate_kernel, rows, blk, stream, (const float*)w.cat, B, H, ev, w.evid, w.gate, forensic);
-  UFND_CHECK_LAUNCH();
-  // 3. stacked q/k/v projections: t -> [q_tv q_ta], v -> [k_tv v_tv q_vu], a -> [k_ta v_ta], u -> [k_vu v_vu]
+  // 2. stacked q/k/v projections: t -> [q_tv q_ta], v -> [k_tv v_tv q_vu], a -> [k_ta v_ta], u -> [k_vu v_vu]
   {
     const int src_slot[4] = {0, 2, 1, 3}, row0[4] = {0, 2, 5, 7}, nrows[4] = {2, 3, 2, 2};
     NtProb pr[4];
@@ -788,10 +800,15 @@ extern "C" int ufnd_fusion_forward(const ufnd_dims* d, const ufnd_fusion_params*
                      w.qkv + (size_t)row0[i] * H, nullptr, B, nrows[i] * H, H, 16 * H, H, 9 * H, 0, 0, 0.0f, 0, 1};
     TRY(launch_nt(pr, 4, state, stream));
   }
-  // 4. co-attention combine + pairwise features -> CAT slots 4..14                    (:44-54,172-178)
-  NI_DISPATCH(H, coattn_pairs_kernel, rows, blk, stream, w.cat, (const float*)w.qkv, (const float*)w.gate, B, H, w.s);
+  // 3. evidence scalars + the three evidence gates (:153-164,48), co-attention combine + pairwise features -> CAT slots
+  //    4..14 (:44-54,172-178): one row kernel
+  EvPtrs ev;
+  for (int b = 0; b < 3; ++b) { ev.w0[b] = p->ev0_w[b]; ev.b0[b] = p->ev0_b[b]; ev.w2[b] = p->ev2_w[b]; ev.b2[b] = p->ev2_b[b]; }
+  if (H == 256) hipLaunchKernelGGL((coattn_pairs_kernel<1, 1>), rows, blk, 0, stream, w.cat, (const float*)w.qkv, w.gate, B, H, w.s, ev, w.evid, forensic);
+  else if (H == 512) hipLaunchKernelGGL((coattn_pairs_kernel<2, 1>), rows, blk, 0, stream, w.cat, (const float*)w.qkv, w.gate, B, H, w.s, ev, w.evid, forensic);
+  else hipLaunchKernelGGL((coattn_pairs_kernel<4, 1>), rows, blk, 0, stream, w.cat, (const float*)w.qkv, w.gate, B, H, w.s, ev, w.evid, forensic);
   UFND_CHECK_LAUNCH();
-  // 5. fuse_mlp.0: (B,16H) x (2H,16H)^T, split-K then bias+GELU(+dropout)             (:122-124)
+  // 4. fuse_mlp.0: (B,16H) x (2H,16H)^T, split-K then bias+GELU(+dropout)             (:122-124)
   {
     NtProb pr{w.cat, p->fuse0_w, nullptr, w.part1, nullptr, B, 2 * H, 16 * H, 16 * H, 16 * H, 2 * H, 0, 0, 0.0f, 0,
               KSPLIT_FUSE0};
@@ -801,12 +818,12 @@ extern "C" int ufnd_fusion_forward(const ufnd_dims* d, const ufnd_fusion_params*
                        KSPLIT_FUSE0, B, 2 * H, (const float*)p->fuse0_b, w.z1, w.h1, 1, drop, LAYER_FUSE0, state);
     UFND_CHECK_LAUNCH();
   }
-  // 6. fuse_mlp.3 + GELU(+dropout) -> fused                                           (:125-127)
+  // 5. fuse_mlp.3 + GELU(+dropout) -> fused                                           (:125-127)
   {
     NtProb pr{w.h1, p->fuse3_w, p->fuse3_b, fused, w.z2, B, H, 2 * H, 2 * H, 2 * H, ld_fused, H, 1, drop, LAYER_FUSE3, 1};
     TRY(launch_nt(&pr, 1, state, stream));
   }
-  // 7. aux head (unused by the trainer's loss, :198)
+  // 6. aux head (unused by the trainer's loss, :198)
   if (logits) {
     hipLaunchKernelGGL(head2_fwd_kernel, rows, blk, 0, stream, (const float*)fused, ld_fused, (const float*)p->cls_w,
                        (const float*)p->cls_b, logits, B, H);
@@ -941,8 +958,8 @@ extern "C" int ufnd_classifier_forward(const ufnd_dims* d, const ufnd_clf_params
   const float drop = train ? d->clf_dropout : 0.0f;
   const dim3 rows(ufnd_cdiv(B, 4)), blk(256);
 
-  hipLaunchKernelGGL(pack_xin_kernel, dim3(B), dim3(128), 0, stream, fused, ld_fused, aux, d->aux_dim, w.xin, w.ldx, B, H,
-                     fused != w.xin ? 1 : 0);
+  hipLaunchKernelGGL(clf_prep_kernel, dim3(B + d->trees * d->depth), blk, 0, stream, fused, ld_fused, aux, d->aux_dim, w.xin, w.ldx, B, H,
+                     fused != w.xin ? 1 : 0, (const float*)p->gates, w.alpha);
   UFND_CHECK_LAUNCH();
   {  // pre.0 / pre.3 + GELU(+dropout)                                    deep_truth_classifier.py:121-128
     NtProb a{w.xin, p->pre0_w, p->pre0_b, w.h3, w.z3, B, H, H + d->aux_dim, w.ldx, H + d->aux_dim, H, H, 1, drop, LAYER_PRE0, 1};
@@ -950,8 +967,6 @@ extern "C" int ufnd_classifier_forward(const ufnd_dims* d, const ufnd_clf_params
     NtProb b{w.h3, p->pre3_w, p->pre3_b, w.hh, w.z4, B, H, H, H, H, H, H, 1, drop, LAYER_PRE3, 1};
     TRY(launch_nt(&b, 1, state, stream));
   }
-  hipLaunchKernelGGL(alpha_kernel, dim3(d->trees * d->depth), blk, 0, stream, (const float*)p->gates, w.alpha, H);
-  UFND_CHECK_LAUNCH();
   NI_DISPATCH(H, node_head_kernel, rows, blk, stream, (const float*)w.hh, (const float*)w.alpha, (const float*)p->thresh,
               (const float*)p->leaf, (const float*)p->tau, (const float*)p->bypass_w, (const float*)p->bypass_b,
               (const float*)p->temperature, B, H, d->trees, d->depth, train ? d->node_dropout : 0.0f, state, w.fs, logits,
@@ -983,16 +998,16 @@ extern "C" int ufnd_classifier_backward(const ufnd_dims* d, const ufnd_clf_param
                      (const float*)w.hh, (const float*)w.alpha, (const float*)w.fs, B, H, d->trees, d->depth, ndrop, state,
                      g->gates, g->thresh, g->leaf, g->bypass_w, g->bypass_b);
   UFND_CHECK_LAUNCH();
-  {  // pre.3
-    TnProb t{w.dz4, w.h3, g->pre3_w, g->pre3_b, B, H, H, H, H, H};
-    TRY(launch_tn(&t, 1, fj.dw()));
+  {  // pre.3: dX -> dz3 (epilogue applies gelu'(z3) * mask)
     NnProb n{w.dz4, p->pre3_w, w.dz3, w.z3, nullptr, B, H, H, H, H, H, H, 0, drop, LAYER_PRE0, H, 1};
     TRY(launch_nn(&n, 1, state, stream));
   }
-  {  // pre.0: dW over the full (hidden + aux) width, dX only over the fused columns
+  {  // both dW products of the module in one grouped launch (pre.0 over the full (hidden + aux) width), then pre.0's dX
+     // over the fused columns only
     fj.fork(6);   // dz3 is ready
-    TnProb t{w.dz3, w.xin, g->pre0_w, g->pre0_b, B, H, H + d->aux_dim, H, w.ldx, H + d->aux_dim};
-    TRY(launch_tn(&t, 1, fj.dw()));
+    TnProb t[2] = {TnProb{w.dz4, w.h3, g->pre3_w, g->pre3_b, B, H, H, H, H, H},
+                   TnProb{w.dz3, w.xin, g->pre0_w, g->pre0_b, B, H, H + d->aux_dim, H, w.ldx, H + d->aux_dim}};
+    TRY(launch_tn(t, 2, fj.dw()));
     NnProb n{w.dz3, p->pre0_w, d_fused, nullptr, nullptr, B, H, H, H, H + d->aux_dim, ld_dfused, 0, 0, 0.0f, 0, 0, 1};
     TRY(launch_nn(&n, 1, state, stream));
   }

@@ -27,6 +27,7 @@ class FusedAdamW:
         self.param_groups: List[dict] = [{"lr": lr, "initial_lr": lr, "weight_decay": weight_decay, "betas": betas,
                                           "eps": eps}]
         self._partials = torch.empty(1024, dtype=torch.float32, device=arena.device)
+        self.fused = True          # ufnd_clip_adamw_step (two launches) instead of norm + finalize + AdamW + advance (four)
         arena.ensure_grad()
         arena.ensure_moments()
 
@@ -43,6 +44,10 @@ class FusedAdamW:
         a, dev = self.arena, self.arena.device
         s = L.stream_ptr(dev)
         lib = L.lib()
+        if self.fused:       # two launches: sum of squares (+ step counter), then norm / clip / AdamW
+            L.check(lib.ufnd_clip_adamw_step(a.data.data_ptr(), a.grad.data_ptr(), a.exp_avg.data_ptr(), a.exp_avg_sq.data_ptr(), a.n_grad,
+                                             self._partials.data_ptr(), self.state.ptr, s), "ufnd_clip_adamw_step")
+            return
         L.check(lib.ufnd_grad_norm(a.grad.data_ptr(), a.n_grad, self._partials.data_ptr(), self.state.ptr, s),
                 "ufnd_grad_norm")
         L.check(lib.ufnd_adamw_step(a.data.data_ptr(), a.grad.data_ptr(), a.exp_avg.data_ptr(),
