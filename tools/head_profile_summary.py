@@ -18,6 +18,12 @@ def short(n):
     return n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:60]
 
 
+# steady state only: the launches between the (steps - 40)-th and the last optimizer kernel (warm-up, graph capture and
+# the buffers' initial copies are before that)
+opt = [i for i, r in enumerate(rows) if "adamw" in r["Kernel_Name"]]
+keep = min(40, len(opt) - 1)
+rows = rows[opt[-keep - 1] + 1:opt[-1] + 1]
+steps = keep
 agg = collections.defaultdict(list)
 for r in rows:
     agg[(short(r["Kernel_Name"]), int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]) * int(r["Grid_Size_Y"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
@@ -26,7 +32,7 @@ ju = json.loads([l for l in open(unprof_json) if l.startswith('{"metric"')][-1])
 shutil.copy(unprof_json, f"profiles/{tag}_unprofiled.json")
 with open(f"profiles/{tag}_summary.md", "w") as f:
     f.write(f"# {tag}: head-only step (cached features), B = 32\n\nCommand: `rocprofv3 --kernel-trace --stats --output-format csv -d ... -- python3 bench.py "
-            f"--head-only --steps 50 --warmup 10 --repeats 1` ({steps} steps in the trace incl. warm-up and graph capture).\n\n")
+            f"--head-only --steps 50 --warmup 10 --repeats 1`; the table covers the last {steps} steps of the trace (steady state).\n\n")
     f.write(f"Unprofiled, same box: **{ju['value']} samples/s, {ju['ms_per_step']} ms/step**, {ju['roofline']['algorithmic_MB_per_step']} MB algorithmic "
             f"=> **{ju['roofline']['achieved']} GB/s = {ju['roofline']['frac']} of 8 TB/s** (`profiles/{tag}_unprofiled.json`).  Under the profiler: "
             f"{jp['ms_per_step']} ms/step.\n\n")
