@@ -47,16 +47,18 @@ def gemm_flops_per_step(B: int) -> tuple[float, int]:
 
 def gemm_bytes_per_step(B: int) -> float:
     """Algorithmic HBM bytes of the same launches: bf16 operands in, bf16 rows out; the two residual GEMMs of a layer
-    also read the fp32 residual stream and write it back (fp32 + bf16 + 8 B of statistics per 32 columns)."""
+    also read the fp32 residual stream and write it back (fp32 + bf16 + 8 B of statistics per 32 columns).  The text
+    encoder's fused projection + attention launch (L = 128) reads X and the stacked weight and writes ctx only."""
     H, I3 = 768, 3072
 
     def g(M, N, K, residual):
         return 2.0 * (M * K + N * K + M * N) + ((8.0 + 0.25) * M * N if residual else 0.0)
 
-    def layer(M):
-        return g(M, 3 * H, H, False) + g(M, H, H, True) + g(M, I3, H, False) + g(M, H, I3, True)
+    def layer(M, fused_attention):
+        qkv = 2.0 * (M * H + 3 * H * H + M * H) if fused_attention else g(M, 3 * H, H, False)
+        return qkv + g(M, H, H, True) + g(M, I3, H, False) + g(M, H, I3, True)
     n = B * FRAMES
-    return 12 * layer(B * SEQ_LEN) + 12 * layer(n * 50) + (2.0 * (n * 49 * 3072 + H * 3072) + 4.0 * n * 49 * H) + 2.0 * (n * H + 512 * H) + 4.0 * n * 512
+    return 12 * layer(B * SEQ_LEN, SEQ_LEN == 128) + 12 * layer(n * 50, False) + (2.0 * (n * 49 * 3072 + H * 3072) + 4.0 * n * 49 * H) + 2.0 * (n * H + 512 * H) + 4.0 * n * 512
 
 
 def pmc_traffic():
