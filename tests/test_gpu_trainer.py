@@ -177,3 +177,39 @@ def test_two_launch_optimizer_is_bit_identical_to_the_four_launch_form(tmp_path)
     assert any(s[2] < 1.0 for s in res[0][3])                 # the clip really was active
     for a, b in zip(res[0][:3], res[1][:3]):
         assert torch.equal(a, b)
+
+
+def test_two_phase_backward_writes_the_same_gradients_as_one_phase(tmp_path):
+    """ufnd_fusion_backward_phase(FUSE_MLP) + (REST) == ufnd_fusion_backward, every gradient bit for bit (the bucketed
+    exchange relies on it), and after the first phase alone the [classifier | fuse_mlp] bucket is already final."""
+    import ctypes as C
+    from ultrafnd_git_amd import _lib as L
+    torch.manual_seed(21)
+    tr = _trainer(tmp_path, 8, False)
+    tr.fusion.train(); tr.clf.train()
+    batch = next(iter(tr.train_loader))
+    B = 8
+    b = tr._bufs(B, True)
+    tr._load_batch(b, batch, "train")
+    tr._enqueue_forward(b, B, True, True)
+    tr.arena.grad.fill_(float("nan"))
+    tr._enqueue_backward(b, B, 0)
+    torch.cuda.synchronize()
+    whole = tr.arena.grad.clone()
+    live = torch.isfinite(whole)                      # (alignment padding between parameter groups is never written)
+    assert int(live.sum()) == 12_745_949
+    cut = tr.reducer.buckets[0][1]
+    tr.arena.grad.fill_(float("nan"))
+    tr._enqueue_backward(b, B, 1)
+    torch.cuda.synchronize()
+    g1 = tr.arena.grad.clone()
+    assert torch.equal(g1[:cut][live[:cut]], whole[:cut][live[:cut]])       # bucket 0 complete after phase 1
+    assert torch.isnan(g1[cut:]).all()                                       # ... and phase 1 did not touch the rest
+    tr._enqueue_backward(b, B, 2)
+    torch.cuda.synchronize()
+    assert torch.equal(tr.arena.grad[live], whole[live]) and torch.equal(torch.isfinite(tr.arena.grad), live)
+    rc = L.lib().ufnd_fusion_backward_phase(C.byref(b["dims"]), C.byref(tr.fusion.param_table()), C.byref(tr.fusion.grad_table()),
+                                            b["text"].data_ptr(), b["audio"].data_ptr(), b["visual"].data_ptr(), b["temporal"].data_ptr(),
+                                            b["gnn"].data_ptr(), B, 1, b["fws"].data_ptr(), b["dfused"].data_ptr(), tr.fusion.hidden, None,
+                                            tr.optim.state.ptr, None, None, 1, 7)
+    assert rc == 1 and b"phase" in L.lib().ufnd_last_error()

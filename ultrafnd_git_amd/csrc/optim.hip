@@ -4,7 +4,27 @@
 // whole optimizer is two streaming passes: 4 B/param read for the norm, 28 B/param for AdamW.
 #include "common.hpp"
 
+// The update of one element is ONE function shared by both AdamW kernels, with every fused multiply-add spelled out and
+// implicit contraction off: the two-launch and the four-launch form of the optimizer must produce the same bits, and a
+// compiler is free to contract a*b + c*d either way round in two separately compiled kernels (it did).
+#pragma clang fp contract(off)
+
 namespace {
+
+struct AdamScalars { float b1, b2, eps, decay, gs, step_size, inv_bc2; };
+__device__ __forceinline__ void adamw_vec(f32x4& pp, f32x4& mm, f32x4& vv, const f32x4 g_raw, const AdamScalars& k) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float gq = g_raw[q] * k.gs;
+    const float pq = pp[q] * k.decay;
+    const float mq = __builtin_fmaf(mm[q], k.b1, (1.0f - k.b1) * gq);
+    const float vq = __builtin_fmaf(vv[q], k.b2, ((1.0f - k.b2) * gq) * gq);
+    const float denom = __builtin_fmaf(sqrtf(vq), k.inv_bc2, k.eps);
+    pp[q] = __builtin_fmaf(-k.step_size, mq / denom, pq);
+    mm[q] = mq;
+    vv[q] = vq;
+  }
+}
 
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* g, size_t n4, float* partials) {
   __shared__ float sh[4];
@@ -53,19 +73,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
   const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
   f32x4* m4 = reinterpret_cast<f32x4*>(m);
   f32x4* v4 = reinterpret_cast<f32x4*>(v);
+  const AdamScalars k{b1, b2, eps, decay, gs, step_size, inv_bc2};
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     f32x4 pp = p4[i], mm = m4[i], vv = v4[i];
-    const f32x4 gg = g4[i] * gs;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float gq = gg[q];
-      float pq = pp[q] * decay;
-      const float mq = mm[q] * b1 + (1.0f - b1) * gq;
-      const float vq = vv[q] * b2 + (1.0f - b2) * gq * gq;
-      const float denom = sqrtf(vq) * inv_bc2 + eps;
-      pq -= step_size * (mq / denom);
-      pp[q] = pq; mm[q] = mq; vv[q] = vq;
-    }
+    adamw_vec(pp, mm, vv, g4[i], k);
     p4[i] = pp; m4[i] = mm; v4[i] = vv;
   }
 }
@@ -125,19 +136,10 @@ __global__ __launch_bounds__(256) void adamw_clip_kernel(float* p, const float* 
   const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
   f32x4* m4 = reinterpret_cast<f32x4*>(m);
   f32x4* v4 = reinterpret_cast<f32x4*>(v);
+  const AdamScalars k{b1, b2, eps, decay, gs, step_size, inv_bc2};
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     f32x4 pp = p4[i], mm = m4[i], vv = v4[i];
-    const f32x4 gg = g4[i] * gs;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float gq = gg[q];
-      float pq = pp[q] * decay;
-      const float mq = mm[q] * b1 + (1.0f - b1) * gq;
-      const float vq = vv[q] * b2 + (1.0f - b2) * gq * gq;
-      const float denom = sqrtf(vq) * inv_bc2 + eps;
-      pq -= step_size * (mq / denom);
-      pp[q] = pq; mm[q] = mq; vv[q] = vq;
-    }
+    adamw_vec(pp, mm, vv, g4[i], k);
     p4[i] = pp; m4[i] = mm; v4[i] = vv;
   }
 }
