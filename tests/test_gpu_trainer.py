@@ -213,3 +213,34 @@ def test_two_phase_backward_writes_the_same_gradients_as_one_phase(tmp_path):
                                             b["gnn"].data_ptr(), B, 1, b["fws"].data_ptr(), b["dfused"].data_ptr(), tr.fusion.hidden, None,
                                             tr.optim.state.ptr, None, None, 1, 7)
     assert rc == 1 and b"phase" in L.lib().ufnd_last_error()
+
+
+def test_fit_with_encoders_inside_the_step_and_the_per_epoch_fold_guard(tmp_path):
+    """fit() over a cache of RAW inputs (token ids, masks, frames) with small encoders inside the step: the epoch loop's
+    plain train_step path, the evaluation path, and the once-per-epoch guarded pass of both encoders (fold guard)."""
+    from oracle import encoders_ref as E
+    from ultrafnd_git_amd.encoders import BertTextEncoder, ClipVisualEncoder
+    from ultrafnd_git_amd.trainer import ForensicTrainer, TrainConfig, synthetic_cache
+    tenc, venc = BertTextEncoder(layers=2, vocab_size=500), ClipVisualEncoder(layers=2)
+    tenc.load_state_dict(E.seeded_weights(E.bert_shapes(layers=2, vocab=500), 11))
+    venc.load_state_dict(E.seeded_weights(E.vit_shapes(layers=2), 12))
+    tenc, venc = tenc.to(DEV), venc.to(DEV)
+    cache = synthetic_cache(48, seed=2, with_raw=True, seq_len=128, vocab=500)
+    cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir=str(tmp_path), batch_size=8, epochs=2, device=DEV, encode_inline=True)
+    tr = ForensicTrainer(cfg, cache=cache, text_encoder=tenc, visual_encoder=venc)
+    best = tr.fit()
+    res = tr.test()
+    assert 0.0 <= best <= 1.0 and np.isfinite(res["test_loss"])
+    assert tenc.fold_ln and venc.fold_ln and tenc.fold_ratio() == 0.0       # the guard ran (and was reset) and did not trip
+    # a tripped guard switches the encoder to materialised LayerNorms and drops its captured graph
+    w = tenc.state_dict()
+    w["embeddings.LayerNorm.bias"] = w["embeddings.LayerNorm.bias"] + 30.0
+    w["encoder.layer.0.attention.output.dense.weight"] = w["encoder.layer.0.attention.output.dense.weight"] * 0.01
+    tenc.load_state_dict(w)
+    import warnings
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        tr._epoch_loop(tr.train_loader, "train")
+    assert not tenc.fold_ln and venc.fold_ln and any("materialised" in str(c.message) for c in caught)
+    assert all(e["g_text"] is None for e in tr._enc_bufs.values())
+    tr._epoch_loop(tr.train_loader, "train")              # and training goes on, unfolded
