@@ -121,6 +121,7 @@ extern "C" int ufnd_qkv_attention_bf16(const void* X, const void* Wqkv, const fl
   a.att_scale_log2e = 0.125f * 1.44269504088896340736f;      // 1 / sqrt(64) * log2(e)
   a.m_tiles = B;
   a.n_tiles = heads / 2;
+  a.xcd_cols = (a.n_tiles % 2 == 0 && a.m_tiles >= 4) ? 2 : 1;
   hipLaunchKernelGGL((gemm_bf16_kernel<128, 384, 2, 4, 3, 2, 16, 0, 0, 1, 1>), dim3(a.m_tiles * a.n_tiles), dim3(512), 0, (hipStream_t)stream_, a);
   UFND_CHECK_LAUNCH();
   return UFND_OK;

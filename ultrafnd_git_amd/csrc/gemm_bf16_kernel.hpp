@@ -55,6 +55,7 @@ struct GemmArgs {
   const int32_t* att_mask;   // (M) key mask, 1 = attend (NULL: every key)
   __bf16* att_ctx;           // (M, att_h) attention output
   int att_h;                 // heads * 64 (= rows of each of the three stacked weight blocks)
+  int xcd_cols;              // 1 (0): an XCD takes whole row panels; 2: the two column halves go to XCDs 0-3 / 4-7
   float att_scale_log2e;     // 1 / sqrt(64) * log2(e)
 };
 
@@ -152,7 +153,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     const int q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int m0 = (bid / a.n_tiles) * BM, n0 = (bid % a.n_tiles) * BN;
+  // tile (tm, tn) of this workgroup.  Default: row-major, so an XCD's contiguous share of the grid is a set of whole row
+  // panels (A fetched by one XCD, every weight row by all eight: fabric reads = A + 8 W).  xcd_cols = 2 (wide shapes:
+  // W is the larger operand per launch): the grid is enumerated column-half by column-half, so XCDs 0-3 hold the left half
+  // of the columns and XCDs 4-7 the right half (reads = 2 A + 4 W).
+  int tm = bid / a.n_tiles, tn = bid % a.n_tiles;
+  if (a.xcd_cols == 2) {
+    const int nh = a.n_tiles >> 1, per_half = a.m_tiles * nh;
+    const int half = bid / per_half, rem = bid - half * per_half;
+    tm = rem / nh;
+    tn = half * nh + (rem - tm * nh);
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int wm = wave / WN, wn = wave % WN, fr = lane & (MI - 1), g = lane / MI;   // fragment row, k-group
 
@@ -191,7 +203,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
       const int c = ppos ^ ((r >> 1) & 7);
       int gr = n0 + r;
       gr = gr < a.N ? gr : a.N - 1;
-      if constexpr (ATT) gr = (r >> 7) * a.att_h + (bid % a.n_tiles) * 128 + (r & 127);     // [q | k | v] rows of this head pair
+      if constexpr (ATT) gr = (r >> 7) * a.att_h + tn * 128 + (r & 127);     // [q | k | v] rows of this head pair
       dma16(a.W + (size_t)gr * a.ldw + k0 + c * 8, buf + p * 1024);
     }
   };
@@ -423,7 +435,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
 #pragma unroll
   for (int j = 0; j < NT; ++j) { bj[j] = 0.f; csj[j] = 0.f; }
   // global column of tile column c
-  auto gcol = [&](int c) { return ATT ? (c >> 7) * a.att_h + (bid % a.n_tiles) * 128 + (c & 127) : n0 + c; };
+  auto gcol = [&](int c) { return ATT ? (c >> 7) * a.att_h + tn * 128 + (c & 127) : n0 + c; };
   if (a.bias) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) bj[j] = a.bias[gcol(wn * TN + j * MI + fr)];
@@ -677,7 +689,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
       l += __shfl_xor(l, 32, 64);
       const float inv = 1.0f / l;
       const int q = wq * 32 + qt * 16 + f16;
-      __bf16* dst = a.att_ctx + (size_t)(m0 + q) * a.att_h + ((bid % a.n_tiles) * 2 + hh) * 64 + 4 * g4;
+      __bf16* dst = a.att_ctx + (size_t)(m0 + q) * a.att_h + (tn * 2 + hh) * 64 + 4 * g4;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         bf16x4 ov = {(__bf16)(o[dt][qt][0] * inv), (__bf16)(o[dt][qt][1] * inv), (__bf16)(o[dt][qt][2] * inv), (__bf16)(o[dt][qt][3] * inv)};
@@ -750,6 +762,19 @@ static const TileCfg kTiles[] = {
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
+// Column split of the grid over the XCDs (see the kernel): worth it where the weight operand (N x K) outweighs the
+// activation operand (M x K) per launch AND both halves still give every XCD whole row panels.
+static int xcd_cols_for(int M, int N, int K, int m_tiles, int n_tiles) {
+#ifdef UFND_DIAG
+  static const int forced = [] { const char* e = getenv("UFND_GEMM_XCD_COLS"); return e ? atoi(e) : 0; }();
+  if (forced == 1) return 1;
+  if (forced == 2) return (n_tiles % 2 == 0) ? 2 : 1;
+#endif
+  (void)K;
+  // reads: A + 8 W (row panels) against 2 A + 4 W (column halves): the split pays when A < 4 W, i.e. M < 4 N
+  return (4LL * N > (long long)M && n_tiles % 2 == 0 && m_tiles >= 4) ? 2 : 1;
+}
+
 // mode: 0 plain kernel, 4 LayerNorm-aware kernel (tiles with LN = 1).  Diagnostics build only: 1 / 2 timing
 // ablations (no MFMA / no in-loop DMA; results are garbage), 3 stamps build, 5 LayerNorm-aware stamps build.
 static int launch_cfg(int cfg, int mode, GemmArgs& a, hipStream_t stream) {
@@ -760,6 +785,7 @@ static int launch_cfg(int cfg, int mode, GemmArgs& a, hipStream_t stream) {
   const TileCfg& t = kTiles[cfg];
   a.m_tiles = ufnd_cdiv(a.M, t.bm);
   a.n_tiles = a.N / t.bn;
+  a.xcd_cols = xcd_cols_for(a.M, a.N, a.K, a.m_tiles, a.n_tiles);
   const dim3 grid(a.m_tiles * a.n_tiles), block(t.threads);
 #ifdef UFND_DIAG
 #define UFND_DIAG_LAUNCH(BM_, BN_, WM_, WN_, SA_, SB_, MI_)                                                                             \
