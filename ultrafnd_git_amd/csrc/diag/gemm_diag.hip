@@ -45,3 +45,25 @@ extern "C" int ufnd_diag_gemm_bf16_stamps(const void* A, const void* W, void* ou
   return UFND_OK;
 }
 
+// The fused projection + attention kernel with stamps: 10 uint64 per workgroup -- {s_memtime, s_memrealtime} at entry, first
+// K-step landed, K loop done, END, and (slots 8, 9) projection epilogue done / attention starts.
+extern "C" int ufnd_diag_qkv_attention_stamps(const void* X, const void* Wqkv, const float* bqkv, const int32_t* key_mask, void* ctx, int B,
+                                              int heads, const ufnd_gemm_ln* ln, unsigned long long* stamps, void* stream_) {
+  UFND_REQUIRE(X && Wqkv && ctx && stamps && heads % 2 == 0, "diag qkv_attention: bad argument");
+  const int H = heads * 64;
+  GemmArgs a{(const __bf16*)X, (const __bf16*)Wqkv, bqkv, nullptr, nullptr, nullptr, B * 128, 3 * H, H, H, H, 0, 0, 0, UFND_ACT_NONE, 0, 0, stamps};
+  if (ln && ln->a_stats) {
+    a.a_stats = ln->a_stats; a.colsum = ln->colsum; a.a_parts = ln->a_parts; a.a_eps = ln->a_eps;
+    a.inv_h = 1.0f / (float)ln->width;
+  }
+  a.att_mask = key_mask;
+  a.att_ctx = (__bf16*)ctx;
+  a.att_h = H;
+  a.att_scale_log2e = 0.125f * 1.44269504088896340736f;
+  a.m_tiles = B;
+  a.n_tiles = heads / 2;
+  a.xcd_cols = (a.n_tiles % 2 == 0 && a.m_tiles >= 4) ? 2 : 1;
+  hipLaunchKernelGGL((gemm_bf16_kernel<128, 384, 2, 4, 3, 2, 16, 0, 1, 1, 1>), dim3(a.m_tiles * a.n_tiles), dim3(512), 0, (hipStream_t)stream_, a);
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
   static_assert(WAITN <= 63, "vmcnt range");
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
-  unsigned long long stamp[8];
+  unsigned long long stamp[10];
   if constexpr (DBG) {
     stamp[0] = __builtin_amdgcn_s_memtime();
     stamp[1] = __builtin_amdgcn_s_memrealtime();
@@ -589,6 +589,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     else if (a.act == UFND_ACT_QUICK_GELU) epilogue(IntC<UFND_ACT_QUICK_GELU>{}, IntC<0>{});
     else epilogue(IntC<UFND_ACT_NONE>{}, IntC<0>{});
   }
+  if constexpr (ATT && DBG) {
+    stamp[8] = __builtin_amdgcn_s_memtime();       // projection epilogue done (images written), attention starts
+    stamp[9] = __builtin_amdgcn_s_memrealtime();
+  }
   if constexpr (ATT) {
     // ---- attention of the tile's two heads on the LDS images (attention.hip's per-wave schedule, L = 128 = two key blocks)
     constexpr float NEG_MASK = -3.0e38f;
@@ -702,8 +706,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     stamp[6] = __builtin_amdgcn_s_memtime();
     stamp[7] = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x == 0) {
+      constexpr int NS = ATT ? 10 : 8;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) a.stamps[(size_t)blockIdx.x * 8 + i] = stamp[i];
+      for (int i = 0; i < NS; ++i) a.stamps[(size_t)blockIdx.x * NS + i] = stamp[i];
     }
   }
 }
