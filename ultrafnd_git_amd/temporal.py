@@ -94,8 +94,8 @@ class TemporalSyncNet(nn.Module):
         return self._packed
 
     @torch.no_grad()
-    def align_batch(self, text: torch.Tensor, visual: torch.Tensor) -> torch.Tensor:
-        """(B,in_dim), (B,Dv) device tensors -> (B,out_dim) device tensor."""
+    def align_batch(self, text: torch.Tensor, visual: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+        """(B,in_dim), (B,Dv) device tensors -> (B,out_dim) device tensor (written into `out` when given)."""
         dev = self.proj[0].weight.device
         if dev.type != "cuda":
             raise L.UltrafndHipError("TemporalSyncNet runs on a HIP device only: call .to('cuda') (no CPU fallback)")
@@ -107,7 +107,10 @@ class TemporalSyncNet(nn.Module):
         if B not in self._ws:
             n = L.lib().ufnd_temporal_workspace_floats(B, self.in_dim, 2 * self.out_dim)
             self._ws[B] = torch.empty(n, dtype=torch.float32, device=dev)
-        out = torch.empty(B, self.out_dim, dtype=torch.float32, device=dev)
+        if out is None:
+            out = torch.empty(B, self.out_dim, dtype=torch.float32, device=dev)
+        elif tuple(out.shape) != (B, self.out_dim) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev:
+            raise RuntimeError(f"align_batch: out must be a contiguous fp32 ({B},{self.out_dim}) tensor on {dev}")
         p = float(self.proj[2].p) if self.training else 0.0
         st = None
         if p > 0.0:                  # device-resident counter: every call draws a fresh mask (stream-ordered, no host copy)

@@ -546,6 +546,25 @@ class ForensicTrainer:
             t.record_stream(sv)
         self._feat_ready[slot] = (ev_t, ev_v)
 
+    def _stage_small_inputs(self, b: dict, batch, B: int) -> None:
+        """audio / aux / label / gnn rows of a raw batch into the step's static buffers: ONE ufnd_gather_rows launch (identity
+        index) instead of four copy kernels on the head -> exchange -> optimizer chain; torch copies when a tensor does not
+        have the buffer's dtype / layout."""
+        pairs = [(batch["audio_features"], b["audio"]), (batch["aux"], b["aux"]), (batch["label"], b["label"]), (batch["gnn_feat"], b["gnn"])]
+        ok = all(isinstance(src, torch.Tensor) and src.device == dst.device and src.dtype == dst.dtype and src.is_contiguous() and
+                 tuple(src.shape) == tuple(dst.shape) and (src[0].numel() * src.element_size()) % 8 == 0 for src, dst in pairs)
+        if not ok:
+            for src, dst in pairs:
+                dst.copy_(src)
+            return
+        if self._iota is None or self._iota.numel() < B:
+            self._iota = torch.arange(max(B, 256), dtype=torch.int64, device=self.device)
+        items = (L.GatherItem * len(pairs))()
+        for it, (src, dst) in zip(items, pairs):
+            it.src, it.dst, it.row_bytes, it.src_rows = src.data_ptr(), dst.data_ptr(), src[0].numel() * src.element_size(), src.shape[0]
+        L.check(L.lib().ufnd_gather_rows(self._iota.data_ptr(), B, items, len(pairs), L.stream_ptr(self.device)), "ufnd_gather_rows")
+
+    _iota: Optional[torch.Tensor] = None
     _timeline: Optional[list] = None     # tools/step_timeline.py sets a list: (tag, timing event) pairs are appended
 
     def _mark(self, tag: str, stream) -> None:
@@ -586,10 +605,9 @@ class ForensicTrainer:
             main.wait_event(ev)
         self._feat_ready[slot] = None
         self._mark("head0", main)
-        for k_src, k_dst in (("audio_features", "audio"), ("aux", "aux"), ("label", "label"), ("gnn_feat", "gnn")):
-            b[k_dst].copy_(batch[k_src])
-        if self.temporal_net is not None:      # fakesv_dataset.py:176: U = tsync.align(T, V)
-            b["temporal"].copy_(self.temporal_net.align_batch(b["text"], b["visual"]))
+        self._stage_small_inputs(b, batch, B)
+        if self.temporal_net is not None:      # fakesv_dataset.py:176: U = tsync.align(T, V), written straight into the step's buffer
+            self.temporal_net.align_batch(b["text"], b["visual"], out=b["temporal"])
         else:
             b["temporal"].copy_(batch["temporal_features"])
         # With a gradient exchange, the next batch's encoders are enqueued BEFORE the head: the RCCL launches inside
