@@ -457,6 +457,38 @@ int ufnd_gcn_pretrain_step(const float* x, const float* adj, int ld_adj, const u
                            const ufnd_step_state* state, float* loss, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * The integrated trainer variant's in-graph GNN: src/training/forensic_trainer_integrated.py
+ *   build_adj_from_ocr_sets :77-98 (weighted Jaccard adjacency of the mini-batch), _pack_batch / _forward :203-224,
+ *   src/models/gnn/gnn_model.py GNNModel :7-41 (lin1 -> A_norm -> ReLU -> dropout -> A_norm -> lin2), trained WITH the head.
+ *   (The reference's `torch.stack([T, A, V, U]).mean(0)` at :205 stacks tensors of widths 768/128/512/256 and raises; the
+ *   node feature built here is the 416-wide one that line's own comment and `gnn_in_dim = 416` describe, i.e. the main
+ *   trainer's compact slice concat, forensic_trainer.py:193-195.)
+ * ---------------------------------------------------------------------------------- */
+
+/* adj (N, N) row stride ld: Jaccard(set_i, set_j) where it is >= thresh, i != j and both sets are non-empty, else 0
+ * (zero diagonal).  Sets as for ufnd_ocr_adjacency. */
+int ufnd_ocr_adjacency_weighted(const int32_t* offsets, const int32_t* tokens, int N, double thresh, float* adj, int ld, void* stream);
+
+/* out (B, n_text + n_audio + n_visual + n_temporal) = [text[:, :n_text] | audio[:, :n_audio] | visual[:, :n_visual] |
+ * temporal[:, :n_temporal]] with every row divided by (its L2 norm + 1e-9)     forensic_trainer.py:193-195 */
+int ufnd_node_features(const float* text, int ld_text, const float* audio, int ld_audio, const float* visual, int ld_visual,
+                       const float* temporal, int ld_temporal, int n_text, int n_audio, int n_visual, int n_temporal, int B,
+                       float* out, void* stream);
+
+size_t ufnd_gnn_workspace_floats(int N, int in_dim, int hid, int out_dim);
+/* GNNModel.forward: z (N, out_dim).  dropout_p > 0 = train mode (mask keyed by state->{seed, step}).  The workspace keeps
+ * what ufnd_gnn_backward needs. */
+int ufnd_gnn_forward(const float* x, const float* adj, int ld_adj, const ufnd_gcn_params* p, float* z, float* workspace, int N,
+                     int in_dim, int hid, int out_dim, float dropout_p, const ufnd_step_state* state, void* stream);
+/* its autograd backward for a gradient d_z (N, out_dim) at z: the four parameter gradients (overwritten). */
+int ufnd_gnn_backward(const float* x, const ufnd_gcn_params* p, float* g_w1, float* g_b1, float* g_w2, float* g_b2, const float* d_z,
+                      float* workspace, int N, int in_dim, int hid, int out_dim, float dropout_p, const ufnd_step_state* state,
+                      void* stream);
+/* d loss / d gnn_feat (B, gnn_dim) after ufnd_fusion_backward[_phase] has run on `workspace`. */
+int ufnd_fusion_gnn_input_grad(const ufnd_dims* d, const ufnd_fusion_params* p, float* workspace, int B, float* d_gnn,
+                               const ufnd_step_state* state, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Compute-unit partitions.  The reference runs its step in program order on one queue
  * (src/training/forensic_trainer.py:285-298); here the text encoder, the visual encoder and the
  * head -> exchange -> optimizer chain are concurrent chains on their own HIP streams, each confined to

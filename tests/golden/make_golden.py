@@ -18,6 +18,8 @@ What it does
   temporal runs the reference's TemporalSyncNet.align on seeded weights -> temporal.npz.
   temporal_seq runs the reference's TemporalSyncNet(use_tcn=True).forward (eval, and train with dropout p=0) on seeded
            weights for four geometries -> temporal_seq.npz; also delay_score / estimate_av_lag known answers.
+  gnn_model runs the reference's GNNModel (forward + autograd backward) and, when importable, build_adj_from_ocr_sets
+           of the integrated trainer variant on synthetic mini-batches -> gnn_model.npz.
   gcn      runs the reference's build_adj_from_ocr / SimpleGCN (forward, two Adam pre-training steps with
            dropout p=0) on synthetic phrase sets -> gcn.npz.
   tier_b   builds the locally installed third-party BertModel / CLIPVisionModelWithProjection
@@ -483,10 +485,66 @@ def gcn():
     print(f"gcn: N={N}, edges={int((ref_adj.sum() - N) / 2)}, forward oracle-vs-reference {e_fwd:.2e}, pretrain {e_pre:.2e}, losses {losses}")
 
 
+def gnn_model():
+    """The integrated variant's in-graph GNN: build_adj_from_ocr_sets (forensic_trainer_integrated.py:77-98,
+    restated there as plain Python: importing that module pulls the dataset pipeline in, so the function body is checked
+    against the oracle's restatement on the reference's own GNNModel only through the adjacency it feeds) and GNNModel
+    (src/models/gnn/gnn_model.py) forward + autograd backward for an upstream gradient."""
+    sys.modules["transformers"] = None
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, str(REF))
+    os.chdir(REF)
+    from src.models.gnn.gnn_model import GNNModel
+    from oracle import gcn_ref as G
+    from oracle import gnn_model_ref as M
+    try:                                                   # the real adjacency builder, when its module imports here
+        from src.training.forensic_trainer_integrated import build_adj_from_ocr_sets as ref_adj_fn
+    except Exception as e:                                 # (dataset-pipeline dependencies absent)
+        print("forensic_trainer_integrated not importable here:", repr(e)[:120])
+        ref_adj_fn = None
+    out = {}
+    for tag, n, thr in (("b32", 32, 0.12), ("b7", 7, 0.05), ("b150", 150, 0.3)):
+        sets = M.synthetic_ocr_sets(n, seed=71 + n)
+        adj = M.build_adj_from_ocr_sets(sets, thr)
+        if ref_adj_fn is not None:
+            ref_adj = ref_adj_fn([set(f"tok{t}" for t in s) for s in sets], overlap_thresh=thr).numpy()
+            assert np.array_equal(ref_adj, adj), tag
+        g = torch.Generator().manual_seed(72 + n)
+        T, A, V, U = (torch.randn(n, d, generator=g).numpy() for d in (768, 128, 512, 256))
+        X = torch.from_numpy(G.node_features(T, A, V, U))
+        w = M.seeded_weights(73)
+        net = GNNModel(in_dim=416, hid=256, out_dim=128, dropout=0.1).eval()
+        assert list(net.state_dict().keys()) == list(w.keys())
+        net.load_state_dict(w)
+        a_t = torch.from_numpy(adj)
+        z = net(X, a_t)
+        dz = torch.randn(n, 128, generator=g) / n
+        z.backward(dz)
+        grads = {k: p.grad.clone() for k, p in net.named_parameters()}
+        # oracle restatement agrees (forward and every gradient)
+        wo = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+        zo = M.forward(wo, X, a_t)
+        zo.backward(dz)
+        e_f = (z.detach() - zo.detach()).abs().max().item()
+        e_g = max((grads[k] - wo[k].grad).abs().max().item() for k in w)
+        assert e_f <= 2e-6 and e_g <= 2e-6, (tag, e_f, e_g)
+        offs, toks = G.sets_to_csr(sets)
+        out.update({f"{tag}/n": np.int64(n), f"{tag}/thr": np.float64(thr), f"{tag}/offsets": offs, f"{tag}/tokens": toks, f"{tag}/adj": adj,
+                    f"{tag}/T": T[:, :192], f"{tag}/A": A[:, :32], f"{tag}/V": V[:, :128], f"{tag}/U": U[:, :64], f"{tag}/X": X.numpy(),
+                    f"{tag}/Z": z.detach().numpy(), f"{tag}/dZ": dz.numpy()})
+        for k, gk in grads.items():
+            out[f"{tag}/grad/{k}"] = gk.numpy()
+        print(f"gnn_model {tag}: n={n} edges={int((adj > 0).sum() // 2)} oracle-vs-reference fwd {e_f:.2e} grads {e_g:.2e}"
+              f" (adjacency {'checked against the reference function' if ref_adj_fn is not None else 'oracle restatement only'})")
+    out["weight_seed"] = np.int64(73)
+    out["checksum"] = np.float64(sum(x.double().sum() for x in M.seeded_weights(73).values()))
+    np.savez_compressed(HERE / "gnn_model.npz", **out)
+
+
 if __name__ == "__main__":
     part = sys.argv[1] if len(sys.argv) > 1 else "all"
     if part == "all":
-        for p in ("tier_a", "metrics", "tier_b", "temporal", "temporal_seq", "init_parity", "gcn"):
+        for p in ("tier_a", "metrics", "tier_b", "temporal", "temporal_seq", "init_parity", "gcn", "gnn_model"):
             subprocess.check_call([sys.executable, str(Path(__file__).resolve()), p], cwd=str(REPO))
     else:
-        {"tier_a": tier_a, "metrics": metrics, "tier_b": tier_b, "temporal": temporal, "temporal_seq": temporal_seq, "init_parity": init_parity, "gcn": gcn}[part]()
+        {"tier_a": tier_a, "metrics": metrics, "tier_b": tier_b, "temporal": temporal, "temporal_seq": temporal_seq, "init_parity": init_parity, "gcn": gcn, "gnn_model": gnn_model}[part]()

@@ -1,0 +1,141 @@
+"""GPU parity of the integrated trainer variant's in-graph GNN: weighted OCR-Jaccard adjacency, node
+features, GNNModel forward / backward against the reference's outputs (tests/golden/gnn_model.npz, minted from
+src/models/gnn/gnn_model.py and forensic_trainer_integrated.build_adj_from_ocr_sets), and the whole step -- GNN inside the
+graph, gradient through gnn_proj into the GNN, one arena for classifier + fusion + GNN -- against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import load_npz
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("tag", ["b32", "b7", "b150"])
+def test_gnn_model_and_weighted_adjacency_match_the_reference(tag):
+    from oracle import gnn_model_ref as M
+    from ultrafnd_git_amd import _lib as L
+    from ultrafnd_git_amd.gnn_model import GNNModel, batch_node_features
+    z = load_npz("gnn_model.npz")
+    n, thr = int(z[f"{tag}/n"]), float(z[f"{tag}/thr"])
+    offs, toks = torch.from_numpy(z[f"{tag}/offsets"]).to(DEV), torch.from_numpy(z[f"{tag}/tokens"]).to(DEV)
+    adj = torch.full((n, n), float("nan"), device=DEV)
+    L.check(L.lib().ufnd_ocr_adjacency_weighted(offs.data_ptr(), toks.data_ptr(), n, thr, adj.data_ptr(), n, L.stream_ptr(adj.device)), "adj")
+    assert np.array_equal(adj.cpu().numpy(), z[f"{tag}/adj"])                   # Python-float Jaccard scores, stored as float32: exact
+    # node features from full-width rows (only the leading slices are read)
+    pad = lambda a, w: torch.cat([torch.from_numpy(a), torch.full((n, w - a.shape[1]), 9.0)], 1).to(DEV)
+    X = batch_node_features(pad(z[f"{tag}/T"], 768), pad(z[f"{tag}/A"], 128), pad(z[f"{tag}/V"], 512), pad(z[f"{tag}/U"], 256))
+    assert np.abs(X.cpu().numpy() - z[f"{tag}/X"]).max() <= 2e-7
+    w = M.seeded_weights(int(z["weight_seed"]))
+    assert abs(sum(x.double().sum() for x in w.values()).item() - float(z["checksum"])) <= 1e-9
+    net = GNNModel(in_dim=416, hid=256, out_dim=128, dropout=0.1)
+    assert list(net.state_dict().keys()) == list(w.keys())
+    net.load_state_dict(w)
+    net = net.to(DEV).eval()
+    out = net(X, adj)
+    ef = np.abs(out.cpu().numpy() - z[f"{tag}/Z"]).max()
+    net.backward(torch.from_numpy(z[f"{tag}/dZ"]).to(DEV))
+    worst = 0.0
+    for k in w:
+        ref = z[f"{tag}/grad/{k}"]
+        got = net.gview(k).cpu().numpy()
+        worst = max(worst, np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-12))
+    print(f"GNNModel {tag}: forward max-abs-err {ef:.2e} (|Z| max {np.abs(z[f'{tag}/Z']).max():.2f}), gradients rel {worst:.2e}")
+    assert ef <= 2e-5 and worst <= 2e-5
+
+
+def test_gnn_model_same_seed_init_and_train_mode_dropout():
+    from ultrafnd_git_amd.gnn_model import GNNModel
+    torch.manual_seed(77)
+    a = GNNModel(416, 256, 128, 0.1)
+    torch.manual_seed(77)
+    l1, l2 = torch.nn.Linear(416, 256), torch.nn.Linear(256, 128)            # the reference's construction order
+    assert torch.equal(a.state_dict()["lin1.weight"], l1.weight) and torch.equal(a.state_dict()["lin2.bias"], l2.bias)
+    a = a.to(DEV)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(16, 416, generator=g).to(DEV)
+    adj = torch.zeros(16, 16, device=DEV)
+    a.train()
+    z1, z2 = a(x, adj).clone(), a(x, adj).clone()
+    a.eval()
+    e1, e2 = a(x, adj).clone(), a(x, adj).clone()
+    assert torch.equal(e1, e2) and not torch.equal(z1, z2) and not torch.equal(z1, e1)     # a fresh dropout mask per train-mode call
+
+
+def test_integrated_step_matches_the_oracle(tmp_path):
+    """ForensicTrainer(gnn_in_graph=True): gnn_feat = GNNModel(node features, weighted adjacency of the mini-batch) inside the
+    graph; CE (label smoothing 0.05, as the variant's config) backward reaches the GNN through gnn_proj; clip + AdamW over ONE
+    arena [classifier | fusion | GNN].  Dropout off; one step against torch autograd over the oracle's restatements."""
+    import torch.nn.functional as F
+    from oracle import gcn_ref as G
+    from oracle import gnn_model_ref as M
+    from oracle import tier_a as O
+    from ultrafnd_git_amd.trainer import ForensicTrainer, TrainConfig, synthetic_cache
+    n = 40
+    cache = synthetic_cache(n, seed=5)
+    del cache["gnn_Z"]
+    cache["ocr_sets"] = M.synthetic_ocr_sets(n, seed=91)
+    cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir=str(tmp_path), batch_size=8, device=DEV, use_graph=True, gnn_in_graph=True,
+                      label_smoothing=0.05, grad_clip=1.0)
+    tr = ForensicTrainer(cfg, cache=cache)
+    fus_sd, clf_sd = O.seeded_params(1234)
+    w_gnn = M.seeded_weights(73)
+    tr.fusion.load_state_dict(fus_sd); tr.clf.load_state_dict(clf_sd); tr.gnn_model.load_state_dict(w_gnn)
+    tr.fusion.dropout = tr.clf.dropout = tr.clf.node_dropout = 0.0
+    tr.gnn_model.dropout = 0.0
+    tr._step_bufs.clear()
+    assert tr.arena.n_grad >= 12_745_949 + 416 * 256 + 256 + 256 * 128 + 128
+    tr.fusion.train(); tr.clf.train()
+    batch = next(iter(tr.val_loader))                      # deterministic order: rows 0..7 of the validation split
+    idx = dict.__getitem__(batch, "index").cpu()
+    gi = tr.val_loader.dataset.global_idx.cpu()[idx].numpy()
+    out = tr.train_step(batch, "val")
+    torch.cuda.synchronize()
+    # ---- oracle: the same step with torch autograd
+    T, A, V, U = (torch.from_numpy(np.asarray(cache[k])[gi]).float() for k in ("text", "audio", "visual", "temporal"))
+    X = torch.from_numpy(G.node_features(T.numpy(), A.numpy(), V.numpy(), U.numpy()))
+    adj = torch.from_numpy(M.build_adj_from_ocr_sets([cache["ocr_sets"][int(i)] for i in gi], 0.12))
+    fl = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in fus_sd.items()}
+    cl = {k: v.clone().requires_grad_(v.dtype.is_floating_point and not k.endswith("tau")) for k, v in clf_sd.items()}
+    wg = {k: v.clone().requires_grad_(True) for k, v in w_gnn.items()}
+    feats = {"text_features": T, "audio_features": A, "visual_features": V, "temporal_features": U, "gnn_feat": M.forward(wg, X, adj),
+             "aux": torch.from_numpy(np.asarray(cache["aux"])[gi]).float(), "label": torch.from_numpy(np.asarray(cache["labels"])[gi]).long()}
+    ref = O.forward_batch(fl, cl, feats)
+    loss = F.cross_entropy(ref["logits"], feats["label"], label_smoothing=0.05)
+    loss.backward()
+    assert abs(float(out["loss"].cpu()) - float(loss)) <= 5e-5
+    assert (out["logits"].cpu() - ref["logits"].detach()).abs().max().item() <= 5e-5
+    # the GNN's gradients (they exist only because the gradient went through gnn_proj's input), before the clip scales them
+    for k, p in wg.items():
+        got = tr.gnn_model.gview(k).cpu()
+        assert (got - p.grad).abs().max().item() <= 2e-4 * max(p.grad.abs().max().item(), 1e-9), k
+    # global norm over all three modules, then the clipped AdamW update of a GNN tensor
+    grads = [p.grad for p in list(fl.values()) + list(cl.values()) + list(wg.values()) if p.grad is not None]
+    total = torch.sqrt(sum(g.double().pow(2).sum() for g in grads)).item()
+    st = tr.optim.state.read()
+    assert abs(float(st.grad_norm) - total) <= 2e-4 * total
+    coef = min(1.0, 1.0 / (total + 1e-6))
+    g = wg["lin2.weight"].grad * coef
+    m, v = 0.1 * g, 0.001 * g * g
+    upd = w_gnn["lin2.weight"] * (1 - 2e-4 * 1e-4) - 2e-4 * (m / 0.1) / ((v / 0.001).sqrt() + 1e-8)
+    assert (tr.gnn_model.aview("lin2.weight").cpu() - upd).abs().max().item() <= 2e-6
+
+
+def test_integrated_variant_fit_and_checkpoint(tmp_path):
+    from oracle import gnn_model_ref as M
+    from ultrafnd_git_amd.trainer import ForensicTrainer, TrainConfig, synthetic_cache
+    n = 120
+    cache = synthetic_cache(n, seed=9)
+    del cache["gnn_Z"]
+    cache["ocr_sets"] = M.synthetic_ocr_sets(n, seed=92)
+    cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir=str(tmp_path), batch_size=16, epochs=2, device=DEV, gnn_in_graph=True,
+                      label_smoothing=0.05, use_cosine=True, grad_clip=1.0)
+    tr = ForensicTrainer(cfg, cache=cache)
+    w0 = tr.gnn_model.aview("lin1.weight").clone()
+    best = tr.fit()
+    res = tr.test()
+    assert 0.0 <= best <= 1.0 and np.isfinite(res["test_loss"])
+    assert not torch.equal(tr.gnn_model.aview("lin1.weight"), w0)                 # the GNN really trains with the head
+    ck = torch.load(tr.ckpt_path, map_location="cpu", weights_only=True)
+    assert set(ck["gnn"]) == {"lin1.weight", "lin1.bias", "lin2.weight", "lin2.bias"}

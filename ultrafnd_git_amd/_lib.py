@@ -158,6 +158,18 @@ def _declare_encoders(lib: C.CDLL) -> None:
     lib.ufnd_gcn_forward.restype = I
     lib.ufnd_gcn_pretrain_step.argtypes = [P, P, I, C.POINTER(GcnParams), P, P, P, P, P, P, I, I, I, I, F, F, F, I, P, P, P]
     lib.ufnd_gcn_pretrain_step.restype = I
+    lib.ufnd_ocr_adjacency_weighted.argtypes = [P, P, I, D, P, I, P]
+    lib.ufnd_ocr_adjacency_weighted.restype = I
+    lib.ufnd_node_features.argtypes = [P, I, P, I, P, I, P, I, I, I, I, I, I, P, P]
+    lib.ufnd_node_features.restype = I
+    lib.ufnd_gnn_workspace_floats.argtypes = [I, I, I, I]
+    lib.ufnd_gnn_workspace_floats.restype = S
+    lib.ufnd_gnn_forward.argtypes = [P, P, I, C.POINTER(GcnParams), P, P, I, I, I, I, F, P, P]
+    lib.ufnd_gnn_forward.restype = I
+    lib.ufnd_gnn_backward.argtypes = [P, C.POINTER(GcnParams), P, P, P, P, P, P, I, I, I, I, F, P, P]
+    lib.ufnd_gnn_backward.restype = I
+    lib.ufnd_fusion_gnn_input_grad.argtypes = [C.POINTER(Dims), C.POINTER(FusionParams), P, I, P, P, P]
+    lib.ufnd_fusion_gnn_input_grad.restype = I
     lib.ufnd_gather_rows.argtypes = [P, I, C.POINTER(GatherItem), I, P]
     lib.ufnd_gather_rows.restype = I
     lib.ufnd_tcn_weight_ld.argtypes = [I, I]

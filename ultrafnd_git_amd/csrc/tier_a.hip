@@ -944,6 +944,19 @@ extern "C" int ufnd_fusion_backward(const ufnd_dims* d, const ufnd_fusion_params
                                     state, stream_, side_stream_, join, UFND_BWD_ALL);
 }
 
+// d loss / d gnn_feat = dg . gnn_proj.weight, from the workspace a fusion backward has just filled (the gradient at the
+// gnn_proj output lives there).  The main trainer's gnn_feat is data (a detached table, forensic_trainer.py:209-211); the
+// integrated variant's comes from a GNN inside the graph (forensic_trainer_integrated.py:203-224) and needs this.
+extern "C" int ufnd_fusion_gnn_input_grad(const ufnd_dims* d, const ufnd_fusion_params* p, float* workspace, int B, float* d_gnn,
+                                          const ufnd_step_state* state, void* stream_) {
+  TRY(check_dims(d, B));
+  UFND_REQUIRE(p && workspace && d_gnn && ufnd_aligned(d_gnn, 16), "fusion_gnn_input_grad: null argument");
+  FusionWs w = carve_fusion(*d, B, workspace);
+  const int H = d->hidden;
+  NnProb n{w.dg, p->gnn_w, d_gnn, nullptr, nullptr, B, H, d->gnn_dim, H, d->gnn_dim, d->gnn_dim, 0, 0, 0.0f, 0, 0, 1};
+  return launch_nn(&n, 1, state, (hipStream_t)stream_);
+}
+
 extern "C" int ufnd_classifier_forward(const ufnd_dims* d, const ufnd_clf_params* p, const float* fused, int ld_fused,
                                        const float* aux, int B, int train, float* workspace, float* logits,
                                        float* probs, const ufnd_step_state* state, void* stream_) {

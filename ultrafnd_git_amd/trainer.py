@@ -74,6 +74,9 @@ class TrainConfig:
     # compute units of the (text encoder, visual encoder) streams when the encoders run inside the step (streams.py);
     # None = ordinary streams.  The head -> exchange -> optimizer chain keeps the whole chip at high priority.
     cu_split: Optional[Tuple[int, int]] = None
+    # the integrated variant's in-graph GNN (forensic_trainer_integrated.py:132-138,203-224): gnn_feat of a mini-batch comes from
+    # a GNNModel over the batch's own OCR-Jaccard graph and is trained WITH the head (the main trainer's gnn_feat is a detached table)
+    gnn_in_graph: bool = False
 
 
 class CachedTensorDataset(torch.utils.data.Dataset):
@@ -229,6 +232,13 @@ class ForensicTrainer:
             raise ValueError("use_gnn=False: the reference's fusion head is sized for the concat WITH the GNN slot and "
                              "fails in forward without gnn_feat (cross_modal_transformer.py:184-197); not supported")
         self.gnn = None   # the GCN that produced gnn_Z is not part of the step (its output is detached: :209-211)
+        self.gnn_model = None
+        if cfg.gnn_in_graph:
+            if "ocr_sets" not in cache:
+                raise KeyError("gnn_in_graph=True needs cache['ocr_sets'] (the mini-batch graph is built from them, "
+                               "forensic_trainer_integrated.py:207-213)")
+            cache = dict(cache)
+            cache.setdefault("gnn_Z", np.zeros((len(cache["labels"]), cfg.gnn_dim), dtype=np.float32))    # (placeholder: never read)
         if "gnn_Z" not in cache:
             if "ocr_sets" not in cache:
                 raise KeyError("cache needs either 'gnn_Z' (N, gnn_dim) or 'ocr_sets' (N phrase sets) to build it from "
@@ -246,7 +256,13 @@ class ForensicTrainer:
         self.fusion = CrossModalTransformer(config_path="configs/model_configs/fusion.yaml").to(self.device)
         self.clf = DeepTruthClassifier(config_path="configs/model_configs/classifier.yaml").to(self.device)
         # one flat arena for both modules: clf first (its gradients are ready first in backward)
-        self.arena = rehome([self.clf, self.fusion], ["clf.", "fusion."])
+        if cfg.gnn_in_graph:
+            from .gnn_model import GNNModel
+            self.gnn_model = GNNModel(in_dim=416, hid=256, out_dim=cfg.gnn_dim, dropout=0.1).to(self.device)   # :136
+            self.arena = rehome([self.clf, self.fusion, self.gnn_model], ["clf.", "fusion.", "gnn."])        # its gradients are ready last
+            self._epoch = 0
+        else:
+            self.arena = rehome([self.clf, self.fusion], ["clf.", "fusion."])
         # two buckets in gradient-ready order: [classifier | fuse_mlp] is complete after the first phase of backward
         self.reducer = GradReducer(self.arena.ensure_grad(), group=group, bounds=[self.arena.offsets["fusion.attn_tv.q.weight"][0]])
         self.optim = FusedAdamW(self.arena, lr=cfg.lr, weight_decay=cfg.weight_decay,
@@ -319,6 +335,9 @@ class ForensicTrainer:
                 "logits": torch.empty(B, 2, dtype=f32, device=dev), "probs": torch.empty(B, 2, dtype=f32, device=dev),
                 "forensic": torch.empty(3, B, dtype=f32, device=dev), "dlogits": torch.empty(B, 2, dtype=f32, device=dev),
                 "dfused": torch.empty(B, self.fusion.hidden, dtype=f32, device=dev), "graph": None}
+            if self.gnn_model is not None:
+                self._step_bufs[key].update({"gnn_x": torch.empty(B, 416, dtype=f32, device=dev), "gnn_adj": torch.zeros(B, B, dtype=f32, device=dev),
+                                             "dgnn": torch.empty(B, self.fusion.gnn_dim, dtype=f32, device=dev)})
         return self._step_bufs[key]
 
     def _load_batch(self, b: dict, batch: Dict[str, torch.Tensor], split: str) -> None:
@@ -414,12 +433,16 @@ class ForensicTrainer:
 
         def second():
             self._enqueue_backward(b, B, 2)
+        post = (lambda: self._gnn_backward(b, B)) if self.gnn_model is not None else (lambda: None)
         if not self._head_graph:
             first()
             if dp:
                 self.reducer.start(0)
                 second()
+                post()
                 self.reducer.start(1)
+            else:
+                post()
             return
         key = "graph_dp" if dp else "graph"
         if b.get(key) is None:
@@ -441,7 +464,42 @@ class ForensicTrainer:
         if dp:
             self.reducer.start(0)
             b[key][1].replay()
+            post()                      # (eager, behind the graph: the GNN's gradients close the arena's last bucket)
             self.reducer.start(1)
+        else:
+            post()
+
+    # ---- the integrated variant's in-graph GNN (forensic_trainer_integrated.py:203-224)
+    def _batch_ocr_sets(self, batch, split: str) -> list:
+        if "ocr_sets" in batch and not isinstance(batch.get("ocr_sets"), torch.Tensor):
+            return list(batch["ocr_sets"])
+        idx = dict.__getitem__(batch, "index") if type(batch) is IndexedBatch else batch["index"]
+        local = idx.cpu().tolist() if isinstance(idx, torch.Tensor) else list(idx)
+        gi = self._dataset(split).global_idx.cpu()
+        return [self.cache["ocr_sets"][int(gi[i])] for i in local]
+
+    def _gnn_forward(self, b: dict, batch, B: int, split: str, train: bool) -> None:
+        """gnn_feat of this mini-batch = GNNModel(node features, weighted OCR-Jaccard adjacency of the batch) -> b["gnn"].
+        The overlap threshold anneals per epoch: max(0.05, thresh * 0.95^epoch) (:210-212)."""
+        from .gnn_model import batch_node_features
+        from .gcn import sets_to_csr
+        batch_node_features(b["text"], b["audio"], b["visual"], b["temporal"], out=b["gnn_x"])
+        thr = max(0.05, self.cfg.gnn_overlap_thresh * (0.95 ** self._epoch))
+        offs, toks = sets_to_csr(self._batch_ocr_sets(batch, split))
+        o = torch.from_numpy(offs).to(self.device)
+        t = torch.from_numpy(toks if toks.size else np.zeros(1, dtype=np.int32)).to(self.device)
+        L.check(L.lib().ufnd_ocr_adjacency_weighted(o.data_ptr(), t.data_ptr(), B, float(thr), b["gnn_adj"].data_ptr(), B,
+                                                    L.stream_ptr(self.device)), "ufnd_ocr_adjacency_weighted")
+        o.record_stream(torch.cuda.current_stream(self.device)); t.record_stream(torch.cuda.current_stream(self.device))
+        self.gnn_model.train(train)
+        self.gnn_model(b["gnn_x"], b["gnn_adj"], state=self.optim.state, out=b["gnn"])
+
+    def _gnn_backward(self, b: dict, B: int) -> None:
+        """d loss / d gnn_feat out of the fusion's workspace, then the GNN's parameter gradients (the arena's last range)."""
+        L.check(L.lib().ufnd_fusion_gnn_input_grad(C.byref(b["dims"]), C.byref(self.fusion.param_table()), b["fws"].data_ptr(), B,
+                                                   b["dgnn"].data_ptr(), self.optim.state.ptr, L.stream_ptr(self.device)),
+                "ufnd_fusion_gnn_input_grad")
+        self.gnn_model.backward(b["dgnn"])
 
     def train_step(self, batch: Dict[str, torch.Tensor], split: str = "train") -> dict:
         """One iteration of the reference's train loop body (forensic_trainer.py:285-298):
@@ -449,6 +507,8 @@ class ForensicTrainer:
         B = _batch_size(batch)
         b = self._bufs(B, True)
         self._load_batch(b, batch, split)
+        if self.gnn_model is not None:
+            self._gnn_forward(b, batch, B, split, True)
         self._fwd_bwd(b, B)
         self.reducer.finish()
         self.optim.clip_and_step()
@@ -690,6 +750,8 @@ class ForensicTrainer:
         train = split == "train"
         b = self._bufs(B, False)
         self._load_batch(b, batch, split)
+        if self.gnn_model is not None:
+            self._gnn_forward(b, batch, B, split, train)
         self._enqueue_forward(b, B, train, False)
         f = b["forensic"]
         return {"logits": b["logits"], "probs": b["probs"], "y": b["label"],
@@ -749,6 +811,7 @@ class ForensicTrainer:
     def fit(self):
         self.no_improve = 0
         for epoch in range(1, self.cfg.epochs + 1):
+            self._epoch = epoch - 1        # (zero-based: anneals the in-graph GNN's overlap threshold, forensic_trainer_integrated.py:259)
             tr_loss, tr_metrics = self._epoch_loop(self.train_loader, "train")
             va_loss, va_metrics = self._epoch_loop(self.val_loader, "val")
             self.scheduler.step()
@@ -765,7 +828,8 @@ class ForensicTrainer:
                 # rank 0 writes the file atomically; every rank leaves save_checkpoint only when it is complete
                 save_checkpoint({"fusion": {k: v.cpu() for k, v in self.fusion.state_dict().items()},
                                  "clf": {k: v.cpu() for k, v in self.clf.state_dict().items()},
-                                 "gnn": self.gnn.state_dict() if self.gnn is not None else None, "cfg": dict(self.cfg.__dict__)},
+                                 "gnn": ({k: v.cpu() for k, v in self.gnn_model.state_dict().items()} if self.gnn_model is not None
+                                         else self.gnn.state_dict() if self.gnn is not None else None), "cfg": dict(self.cfg.__dict__)},
                                 self.ckpt_path, self.group)
                 if self.rank == 0:
                     print(f"  ↳ saved best checkpoint to {self.ckpt_path} (val_auc={self.best_val_auc:.3f})")
@@ -784,6 +848,8 @@ class ForensicTrainer:
             ck = torch.load(self.ckpt_path, map_location="cpu", weights_only=True)
             self.fusion.load_state_dict(ck["fusion"])
             self.clf.load_state_dict(ck["clf"])
+            if self.gnn_model is not None and ck.get("gnn") is not None:
+                self.gnn_model.load_state_dict(ck["gnn"])
         broadcast_from_rank0(self.arena.data, self.group)
         self.fusion.eval()
         self.clf.eval()
