@@ -44,3 +44,28 @@ def test_pretrain_steps_match_reference():
     assert abs(float(w2["lin2.weight"].double().sum()) - float(z["lin2_w_after_sum"])) <= 1e-4
     out = G.gcn_forward(w2, torch.from_numpy(z["X"]), torch.from_numpy(adj))
     assert (out - torch.from_numpy(z["Z_after"])).abs().max().item() <= 5e-6
+
+
+def test_gnn_model_oracle_matches_the_reference_fixture():
+    """oracle.gnn_model_ref (the integrated variant's GNNModel + weighted adjacency) against tests/golden/gnn_model.npz,
+    which make_golden.py minted from the reference's own GNNModel / build_adj_from_ocr_sets."""
+    import torch
+    from oracle import gcn_ref as G
+    from oracle import gnn_model_ref as M
+    z = load_npz("gnn_model.npz")
+    w = M.seeded_weights(int(z["weight_seed"]))
+    assert abs(sum(x.double().sum() for x in w.values()).item() - float(z["checksum"])) <= 1e-9
+    for tag in ("b32", "b7", "b150"):
+        n, thr = int(z[f"{tag}/n"]), float(z[f"{tag}/thr"])
+        offs, toks = z[f"{tag}/offsets"], z[f"{tag}/tokens"]
+        sets = [set(int(t) for t in toks[offs[i]:offs[i + 1]]) for i in range(n)]
+        adj = M.build_adj_from_ocr_sets(sets, thr)
+        assert np.array_equal(adj, z[f"{tag}/adj"]) and np.array_equal(adj, adj.T) and np.all(np.diag(adj) == 0)
+        X = G.node_features(*(np.pad(z[f"{tag}/{k}"], ((0, 0), (0, 8))) for k in "TAVU"))      # extra columns are never read
+        assert np.abs(X - z[f"{tag}/X"]).max() <= 1e-7
+        wo = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+        out = M.forward(wo, torch.from_numpy(z[f"{tag}/X"]), torch.from_numpy(adj))
+        assert np.abs(out.detach().numpy() - z[f"{tag}/Z"]).max() <= 2e-6
+        out.backward(torch.from_numpy(z[f"{tag}/dZ"]))
+        for k in w:
+            assert np.abs(wo[k].grad.numpy() - z[f"{tag}/grad/{k}"]).max() <= 2e-6, (tag, k)
