@@ -547,6 +547,34 @@ class ForensicTrainer:
     def _encode_vis(self, e: dict) -> None:
         e["vis_out"].copy_(self.visual_encoder(e["frames"]))
 
+    _PINNED_GRAPHS = 8      # captured encoder graphs per encoder that read the CALLER's input buffers in place
+
+    def _encode_pinned(self, e: dict, which: str, enc, inputs: tuple, dtypes: tuple, out: torch.Tensor) -> bool:
+        """Encode straight from the caller's buffers into the step's slot buffer, from a graph captured for exactly these
+        addresses: a loader that rotates a few persistent device buffers (bench.py: four) then pays NO restaging copy (the frames
+        alone were a 19 MB device-to-device copy per step) and no copy of the features.  False when the inputs do not qualify
+        or the cache is full: the caller then stages them into the encoder's static buffers (one graph for any address)."""
+        if not self.cfg.use_graph:
+            return False
+        for t, dt in zip(inputs, dtypes):
+            if not (isinstance(t, torch.Tensor) and t.device == self.device and t.dtype == dt and t.is_contiguous()):
+                return False
+        key = (which,) + tuple(t.data_ptr() for t in inputs) + (out.data_ptr(),)
+        cache = e.setdefault("pinned", {})
+        ent = cache.get(key)
+        if ent is None:
+            if sum(1 for k in cache if k[0] == which) >= self._PINNED_GRAPHS:
+                return False
+            cur = torch.cuda.current_stream(self.device)
+            out.copy_(enc(*inputs))                     # warm-up: packs weights, allocates buffers
+            cur.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=cur, capture_error_mode="thread_local"):
+                out.copy_(enc(*inputs))
+            ent = cache[key] = (g, inputs)              # (the graph names these buffers: keep them alive)
+        ent[0].replay()
+        return True
+
     def _replay_or_capture(self, e: dict, which: str, fn) -> None:
         """Run `fn(e)` on the current stream: eagerly, or (use_graph) from a graph captured once."""
         if not self.cfg.use_graph:
@@ -586,18 +614,25 @@ class ForensicTrainer:
                 strm.wait_event(self._slot_free[slot])   # the head that last used this slot is done with it
         with torch.cuda.stream(st):
             self._mark("text0", st)
-            e["ids"].copy_(ids)
-            e["mask"].copy_(batch["attention_mask"])
-            self._replay_or_capture(e, "g_text", self._encode_text)
-            b["text"].copy_(e["text_out"])
+            mask = batch["attention_mask"]
+            e["last_text"] = (ids, mask)
+            if not self._encode_pinned(e, "text", self.text_encoder, (ids, mask), (torch.int64, torch.int32), b["text"]):
+                e["ids"].copy_(ids)
+                e["mask"].copy_(mask)
+                e["last_text"] = (e["ids"], e["mask"])
+                self._replay_or_capture(e, "g_text", self._encode_text)
+                b["text"].copy_(e["text_out"])
             ev_t = torch.cuda.Event()
             ev_t.record(st)
             self._mark("text1", st)
         with torch.cuda.stream(sv):
             self._mark("vis0", sv)
-            e["frames"].copy_(frames)
-            self._replay_or_capture(e, "g_vis", self._encode_vis)
-            b["visual"].copy_(e["vis_out"])
+            e["last_vis"] = (frames,)
+            if not self._encode_pinned(e, "vis", self.visual_encoder, (frames,), (torch.float32,), b["visual"]):
+                e["frames"].copy_(frames)
+                e["last_vis"] = (e["frames"],)
+                self._replay_or_capture(e, "g_vis", self._encode_vis)
+                b["visual"].copy_(e["vis_out"])
             ev_v = torch.cuda.Event()
             ev_v.record(sv)
             self._mark("vis1", sv)
@@ -785,10 +820,12 @@ class ForensicTrainer:
             # last batch; a row outside the folded LayerNorm's accuracy range switches that encoder to materialised
             # LayerNorms, and its captured graph is rebuilt on the next step
             for e in list(self._enc_bufs.values()):
-                for enc, key, args in ((self.text_encoder, "g_text", (e["ids"], e["mask"])), (self.visual_encoder, "g_vis", (e["frames"],))):
-                    if enc is not None and enc.guarded_pass(*args):
+                for enc, key, tag, args in ((self.text_encoder, "g_text", "text", e.get("last_text")), (self.visual_encoder, "g_vis", "vis", e.get("last_vis"))):
+                    if enc is not None and args is not None and enc.guarded_pass(*args):
                         for e2 in self._enc_bufs.values():
                             e2[key] = None
+                            for k in [k for k in e2.get("pinned", {}) if k[0] == tag]:
+                                del e2["pinned"][k]
         if not losses and self.world == 1:
             return 0.0, aggregate_epoch_metrics(np.array([], dtype=int), np.array([], dtype=float))
         if not losses:      # an empty evaluation shard still takes part in the gather
