@@ -148,6 +148,10 @@ def main():
     ap.add_argument("--cu-split", type=str, default=None, help="compute units of the text,visual encoder streams, e.g. 192,64 (0 = ordinary streams)")
     ap.add_argument("--text-tiles", type=str, default=None, help="experiments: GEMM tile ids of the text encoder, e.g. qkv=22,out=16,ffn1=22,ffn2=16")
     ap.add_argument("--vis-tiles", type=str, default=None, help="experiments: GEMM tile ids of the visual encoder")
+    ap.add_argument("--lookahead", type=int, default=4,
+                    help="encoder lookahead G: the frozen encoders run over G consecutive batches per pass (1 = one batch per pass); "
+                         "the head, the exchange and the optimizer always step batch by batch")
+    ap.add_argument("--no-lookahead-compare", action="store_true", help="skip the lookahead-1 comparison leg")
     ap.add_argument("--no-fuse-attn", action="store_true", help="text encoder: Q/K/V projection and attention as two launches per layer")
     ap.add_argument("--head-only", action="store_true",
                     help="secondary measurement: the reference's actual training mode (cached features, no encoders in the step)")
@@ -230,13 +234,21 @@ def main():
     tr = ForensicTrainer(cfg, cache=synthetic_cache(64, seed=1), text_encoder=tenc, visual_encoder=venc, temporal_net=tsync)
     tr.fusion.train()
     tr.clf.train()
-    batches = make_batches(B, 4, 42 + 2 + 1000 * rank, dev)
+    G = max(1, args.lookahead)
+    batches = make_batches(G * B, 4, 42 + 2 + 1000 * rank, dev)       # four persistent lookahead groups of G batches each (G = 1: four batches)
 
     def run(n):
-        """Software-pipelined steps: the all-reduce of step i overlaps the encoders of step i+1."""
-        tr.prefetch_features(batches[0])
-        for i in range(n):
-            tr.train_step_pipelined(batches[i % 4], batches[(i + 1) % 4] if i + 1 < n else None)
+        """n optimizer steps, software-pipelined: the head / exchange / optimizer of the current batches overlap the encoders of
+        the next ones.  G > 1: encoders once per group of G batches (a last, partial group still encodes all G: never less work)."""
+        if G == 1:
+            tr.prefetch_features(batches[0])
+            for i in range(n):
+                tr.train_step_pipelined(batches[i % 4], batches[(i + 1) % 4] if i + 1 < n else None)
+            return
+        ng = (n + G - 1) // G
+        tr.prefetch_features(batches[0], group=True)
+        for gi in range(ng):
+            tr.train_group_pipelined(batches[gi % 4], batches[(gi + 1) % 4] if gi + 1 < ng else None, steps=min(G, n - gi * G))
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -244,12 +256,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # graph-capture priming (setup, not a step): the loader below rotates four persistent batches through the trainer's two
+    # graph-capture priming (setup, not a step): the loader rotates four persistent input buffers through the trainer's two
     # input slots, and the encoders keep one captured graph per (input buffers, slot) so that nothing is restaged -- capture all
     # eight before the warm-up, so that no capture can fall into a timed block
     for slot in (0, 1):
         for bt in batches:
-            tr.prefetch_features(bt, slot)
+            tr.prefetch_features(bt, slot, group=G > 1)
     torch.cuda.synchronize(dev)
     run(args.warmup)
     blocks = []
@@ -266,17 +278,47 @@ def main():
         blocks.append(dt)
     dt = sorted(blocks)[len(blocks) // 2]      # the median block is the one reported
     final_loss = float(tr.optim.state.read().loss)
+    # the same steps with ONE batch per encoder pass (lookahead 1), in the same run, for comparison: not the headline
+    la1 = None
+    if G > 1 and not args.no_lookahead_compare:
+        singles = [{k: v[:B] for k, v in bt.items()} for bt in batches]         # the first batch of every group (leading rows: contiguous views)
+
+        def run1(n):
+            tr.prefetch_features(singles[0])
+            for i in range(n):
+                tr.train_step_pipelined(singles[i % 4], singles[(i + 1) % 4] if i + 1 < n else None)
+        for slot in (0, 1):
+            for bt in singles:
+                tr.prefetch_features(bt, slot)
+        torch.cuda.synchronize(dev)
+        run1(args.warmup)
+        b1 = []
+        for _ in range(3):
+            fence()
+            t0 = time.perf_counter()
+            run1(args.steps)
+            fence()
+            d1 = time.perf_counter() - t0
+            if dist.is_initialized():
+                t = torch.tensor([d1], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                d1 = float(t.item())
+            b1.append(d1)
+        d1 = sorted(b1)[1]
+        la1 = {"value": round(world * B * args.steps / d1, 2), "ms_per_step": round(d1 / args.steps * 1e3, 4),
+               "what": "the same optimizer steps with one batch per encoder pass (lookahead 1), median of 3 blocks, same process"}
 
     # ---- roofline of the dominant kernel (bf16 GEMM): HIP events around every launch, instrumented pass
     roof = None
     if rank == 0:
-        gem_ms, launches = tr.measure_gemm_time(batches[0], steps=3)
+        gem_ms, launches = tr.measure_gemm_time(batches[0], steps=3)          # one encoder pass = G batches
         flops, n_launch = gemm_flops_per_step(B)
         assert launches == n_launch, (launches, n_launch)
+        gem_ms /= G                                                            # GEMM launch time per optimizer step
         step_ms = dt / args.steps * 1e3
         achieved = flops / (step_ms * 1e-3) / 1e12             # whole step: launches of the two encoder streams overlap in time
         per_launch = flops / (gem_ms * 1e-3) / 1e12
-        headline = (SEQ_LEN, FRAMES, B) == (128, 1, 32) and not args.no_fold_ln
+        headline = (SEQ_LEN, FRAMES, B, G) == (128, 1, 32, 4) and not args.no_fold_ln
         traffic, traffic_src = pmc_traffic() if headline else (None, None)       # (the PMC passes were taken on the headline run)
         raw_us = tr.last_raw_interval_us
         roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
@@ -285,15 +327,16 @@ def main():
                          "launches overlap in time on two streams, so this -- not the sum of launch durations -- is what the driver's "
                          "clock can check; nothing else in the step is credited" % n_launch,
                 "traffic": round(traffic) if traffic else None, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": round(gemm_bytes_per_step(B) / n_launch),
-                "launches_per_step": n_launch, "flops_per_step": flops, "flops_per_launch_avg": flops / n_launch,
+                "algorithmic_bytes_per_launch": round(gemm_bytes_per_step(G * B) / n_launch),
+                "launches_per_encoder_pass": n_launch, "optimizer_steps_per_encoder_pass": G, "flops_per_step": flops,
+                "flops_per_launch_avg": flops * G / n_launch,
                 "per_launch": {"how": "HIP events on the launch stream around every launch, sequential instrumented pass after the timed "
                                       "region (text encoder, then visual encoder); avg_launch_us = raw event interval - marker price, "
                                       "marker price = lower quartile of the event-to-event gaps with no kernel in between",
                                "avg_event_interval_us": round(raw_us, 2), "event_marker_us": round(tr.last_marker_us, 2),
-                               "avg_launch_us": round(gem_ms * 1e3 / n_launch, 2), "gemm_ms_per_step": round(gem_ms, 4),
+                               "avg_launch_us": round(gem_ms * G * 1e3 / n_launch, 2), "gemm_ms_per_step": round(gem_ms, 4),
                                "achieved": round(per_launch, 2), "frac": round(per_launch / MFMA_BF16_PEAK_TFLOPS, 4),
-                               "by_shape_MxNxK": {k: {"launches_per_step": v[0] // 3, "avg_us": round(v[1] / v[0] * 1e3, 2),
+                               "by_shape_MxNxK": {k: {"launches_per_encoder_pass": v[0] // 3, "avg_us": round(v[1] / v[0] * 1e3, 2),
                                                       "tflops": round(2.0 * eval(k.replace("x", "*")) / (v[1] / v[0] * 1e-3) / 1e12, 1)}
                                                   for k, v in tr.last_gemm_by_shape.items()}}}
     cpu = None
@@ -307,14 +350,17 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("BASELINE configs[1]" if (SEQ_LEN, FRAMES, B) == (128, 1, 32) else "variant of BASELINE configs[1]") +
                                    f": full Ultrafnd step (BERT-base L={SEQ_LEN} fwd + {FRAMES} x ViT-B/32 224^2 fwd, frozen; "
-                                   "fusion+classifier fwd/bwd, clip, AdamW)", "per_gpu_batch": B, "global_batch": world * B,
+                                   "fusion+classifier fwd/bwd, clip, AdamW)" +
+                                   (f"; the frozen encoders run over {G} consecutive batches per pass (lookahead: every batch is encoded exactly "
+                                    "once, inside the timed region; features are bit-identical to one-batch passes), one optimizer step per batch" if G > 1 else ""),
+                       "per_gpu_batch": B, "global_batch": world * B, "encoder_lookahead_batches": G,
                        "seq_len": SEQ_LEN, "frames": FRAMES, "image": IMAGE, "parallelism": f"dp{world}",
                        "encoder_dtype": "bf16 operands / fp32 accumulate", "head_dtype": "fp32", "hip_graph": not args.no_graph,
                        "weights": "random init of the named architectures"},
             "timing": {"what": f"median of {len(blocks)} back-to-back blocks of {args.steps} steps, each between barrier + synchronize fences",
                        "ms_per_step_blocks": [round(x / args.steps * 1e3, 4) for x in blocks],
                        "ms_per_step_min": round(min(blocks) / args.steps * 1e3, 4), "ms_per_step_max": round(max(blocks) / args.steps * 1e3, 4)},
-            "final_loss": final_loss, "roofline": roof, "cpu_baseline": cpu}))
+            "lookahead_1": la1, "final_loss": final_loss, "roofline": roof, "cpu_baseline": cpu}))
     if dist.is_initialized():
         dist.destroy_process_group()
 

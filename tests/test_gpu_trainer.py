@@ -244,3 +244,48 @@ def test_fit_with_encoders_inside_the_step_and_the_per_epoch_fold_guard(tmp_path
     assert not tenc.fold_ln and venc.fold_ln and any("materialised" in str(c.message) for c in caught)
     assert all(e["g_text"] is None for e in tr._enc_bufs.values())
     tr._epoch_loop(tr.train_loader, "train")              # and training goes on, unfolded
+
+
+def test_encoder_lookahead_groups_equal_plain_steps(tmp_path):
+    """train_group_pipelined: the frozen encoders run ONCE over G = 3 consecutive batches (128-token samples: the fused
+    projection + attention path), the head steps batch by batch.  Two groups (6 optimizer steps, the second group partial:
+    2 of its 3 batches) leave logits and the whole parameter arena bit-identical to 5 plain train_step calls on the same
+    batches; the per-step losses agree too."""
+    from oracle import encoders_ref as E
+    from ultrafnd_git_amd.encoders import BertTextEncoder, ClipVisualEncoder
+    from ultrafnd_git_amd.temporal import TemporalSyncNet
+    from ultrafnd_git_amd.trainer import ForensicTrainer, TrainConfig, synthetic_cache
+    tenc, venc = BertTextEncoder(layers=2, vocab_size=300).to(DEV), ClipVisualEncoder(layers=1).to(DEV)
+    B, G = 4, 3
+    g = torch.Generator().manual_seed(2)
+
+    def macro(seed):
+        ids, mask = E.synthetic_tokens(seed, G * B, 128, vocab=300, min_len=4)
+        return {"input_ids": ids.to(DEV), "attention_mask": mask.to(torch.int32).to(DEV),
+                "frames": torch.randn(G * B, 1, 3, 224, 224, generator=g).to(DEV), "audio_features": torch.randn(G * B, 128, generator=g).to(DEV),
+                "temporal_features": torch.randn(G * B, 256, generator=g).to(DEV), "gnn_feat": torch.randn(G * B, 128, generator=g).to(DEV),
+                "aux": torch.rand(G * B, 2, generator=g).to(DEV), "label": torch.randint(0, 2, (G * B,), generator=g).to(DEV)}
+    groups = [macro(31), macro(32)]
+    outs = []
+    for mode in ("plain", "lookahead"):
+        torch.manual_seed(7)
+        cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir=str(tmp_path), batch_size=B, device=DEV, encode_inline=True)
+        tsync = TemporalSyncNet(in_dim=768, out_dim=256).to(DEV).eval()
+        tr = ForensicTrainer(cfg, cache=synthetic_cache(16, seed=1), text_encoder=tenc, visual_encoder=venc, temporal_net=tsync)
+        tr.fusion.train(); tr.clf.train()
+        losses = []
+        if mode == "plain":
+            for gi, steps in ((0, 3), (1, 2)):
+                for k in range(steps):
+                    out = tr.train_step({key: v[k * B:(k + 1) * B].contiguous() for key, v in groups[gi].items()})
+                    losses.append(float(out["loss"].cpu()))
+        else:
+            tr.prefetch_features(groups[0], group=True)
+            out = tr.train_group_pipelined(groups[0], groups[1])
+            losses += [float(x.cpu()) for x in out["losses"]]
+            out = tr.train_group_pipelined(groups[1], None, steps=2)
+            losses += [float(x.cpu()) for x in out["losses"]]
+        torch.cuda.synchronize()
+        outs.append((out["logits"].clone(), tr.arena.data.clone(), losses, int(tr.optim.state.read().step)))
+    assert outs[0][3] == outs[1][3] == 5 and outs[0][2] == outs[1][2]
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

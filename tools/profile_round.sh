@@ -11,10 +11,10 @@ O=gpurun_out/$1
 mkdir -p $O
 rm -rf $O/prof $O/pmc_fetch $O/pmc_write $O/pmc_mfma $O/prof_head
 python3 bench.py --steps 20 --warmup 5 > $O/bench_unprofiled.json 2> $O/bench_unprofiled.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --repeats 1 > $O/bench_profiled.json 2> $O/bench_profiled.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --repeats 1 > $O/pmc_fetch.json 2> $O/pmc_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --repeats 1 > $O/pmc_write.json 2> $O/pmc_write.err
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --repeats 1 > $O/pmc_mfma.json 2> $O/pmc_mfma.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-lookahead-compare --repeats 1 > $O/bench_profiled.json 2> $O/bench_profiled.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-lookahead-compare --repeats 1 > $O/pmc_fetch.json 2> $O/pmc_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-lookahead-compare --repeats 1 > $O/pmc_write.json 2> $O/pmc_write.err
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-lookahead-compare --repeats 1 > $O/pmc_mfma.json 2> $O/pmc_mfma.err
 python3 bench.py --head-only --steps 200 --warmup 20 > $O/head_unprofiled.json 2> $O/head_unprofiled.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_head -- python3 bench.py --head-only --steps 50 --warmup 10 --repeats 1 > $O/head_profiled.json 2> $O/head_profiled.err
 UFND_FORCE_REDUCE=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --head-only --steps 200 --warmup 20 > $O/head_dp1.json 2> $O/head_dp1.err

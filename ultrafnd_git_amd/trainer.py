@@ -297,6 +297,10 @@ class ForensicTrainer:
         self._slot = 0
         self._feat_ready = [None, None]
         self._slot_free = [None, None]
+        self._gslot = 0                      # encoder lookahead (train_group_pipelined): group feature buffers, two slots
+        self._grp_bufs: Dict[Tuple[int, int], dict] = {}
+        self._grp_ready = [None, None]
+        self._grp_free = [None, None]
 
     # ------------------------------------------------------------------ data
     def _build_dataloaders(self):
@@ -591,16 +595,19 @@ class ForensicTrainer:
         e[which].replay()
 
     def prefetch_features(self, batch: Dict[str, torch.Tensor], slot: Optional[int] = None,
-                          inputs_ready: Optional[torch.cuda.Event] = None) -> None:
+                          inputs_ready: Optional[torch.cuda.Event] = None, group: bool = False) -> None:
         """Encode `batch` on the two encoder streams (text || visual) into input slot `slot` of the step
         buffers.  Runs concurrently with whatever the compute stream is doing (the fusion head of the
-        previous batch); `_feat_ready[slot]` is recorded when both features have landed."""
-        slot = self._slot if slot is None else slot
+        previous batch); `_feat_ready[slot]` is recorded when both features have landed.
+        group=True: `batch` is a lookahead group (G x batch_size rows, train_group_pipelined): the features go to the group
+        feature buffers of group slot `slot`, and `_grp_ready[slot]` is recorded."""
+        slot = (self._gslot if group else self._slot) if slot is None else slot
         ids, frames = batch["input_ids"], batch["frames"]
         if frames.dim() == 4:
             frames = frames[:, None]
         B, Lq, Fr = int(ids.shape[0]), int(ids.shape[1]), int(frames.shape[1])
-        b = self._bufs(B, True, slot)
+        b = self._group_bufs(B, slot) if group else self._bufs(B, True, slot)
+        free = self._grp_free if group else self._slot_free
         e = self._enc_state(B, Lq, Fr, int(frames.shape[-1]))
         main = torch.cuda.current_stream(self.device)
         st, sv = self._enc_streams
@@ -610,8 +617,8 @@ class ForensicTrainer:
                 strm.wait_event(inputs_ready)
             else:
                 strm.wait_stream(main)
-            if self._slot_free[slot] is not None:
-                strm.wait_event(self._slot_free[slot])   # the head that last used this slot is done with it
+            if free[slot] is not None:
+                strm.wait_event(free[slot])   # the head(s) that last read this slot are done with it
         with torch.cuda.stream(st):
             self._mark("text0", st)
             mask = batch["attention_mask"]
@@ -639,7 +646,97 @@ class ForensicTrainer:
         for t in (ids, batch["attention_mask"], frames):
             t.record_stream(st)
             t.record_stream(sv)
-        self._feat_ready[slot] = (ev_t, ev_v)
+        if group:
+            self._grp_ready[slot] = (ev_t, ev_v)
+        else:
+            self._feat_ready[slot] = (ev_t, ev_v)
+
+    # ---- encoder lookahead: the frozen encoders run over G consecutive batches per pass, the head steps batch by batch
+    def _group_bufs(self, GB: int, gslot: int) -> dict:
+        key = (GB, gslot)
+        if key not in self._grp_bufs:
+            self._grp_bufs[key] = {"text": torch.empty(GB, 768, dtype=torch.float32, device=self.device),
+                                   "visual": torch.empty(GB, 512, dtype=torch.float32, device=self.device)}
+        return self._grp_bufs[key]
+
+    def train_group_pipelined(self, group: Dict[str, torch.Tensor], next_group: Optional[Dict[str, torch.Tensor]],
+                              steps: Optional[int] = None) -> dict:
+        """`steps` (default: all G) optimizer steps over a lookahead group: a dict of raw inputs with G x batch_size rows whose
+        features prefetch_features(group=True) has started.  The encoders are frozen (as in the reference, where the features
+        are a precomputed cache), so encoding G batches in ONE pass changes no value -- a row's features do not depend on the
+        batch it is encoded in, bit for bit (test) -- while every GEMM launch gets G times the rows: fewer, larger launches.
+        The head, the loss, the gradient exchange, the clip and AdamW run per batch of batch_size rows, in order, exactly as
+        train_step does: G optimizer steps.  The next group's encoders are enqueued behind the first head."""
+        if self._hp_stream is None:
+            self._hp_stream = torch.cuda.Stream(device=self.device, priority=-1)
+        caller = torch.cuda.current_stream(self.device)
+        self._hp_stream.wait_stream(caller)
+        with torch.cuda.stream(self._hp_stream):
+            out = self._train_group_pipelined(group, next_group, steps)
+        caller.wait_stream(self._hp_stream)
+        return out
+
+    def _train_group_pipelined(self, group, next_group, steps) -> dict:
+        B = int(self.cfg.batch_size)
+        GB = int(group["input_ids"].shape[0])
+        if GB % B:
+            raise RuntimeError(f"lookahead group of {GB} rows is not a multiple of batch_size {B}")
+        G = GB // B
+        steps = G if steps is None else int(steps)
+        gslot = self._gslot
+        grp = self._group_bufs(GB, gslot)
+        main = torch.cuda.current_stream(self.device)
+        if self._grp_ready[gslot] is None:
+            raise RuntimeError("train_group_pipelined: call prefetch_features(group, group=True) for the first group")
+        inputs_ready = torch.cuda.Event()
+        inputs_ready.record(main)
+        self._mark("step0", main)
+        for ev in self._grp_ready[gslot]:
+            main.wait_event(ev)
+        self._grp_ready[gslot] = None
+        self._mark("head0", main)
+        b = self._bufs(B, True, 0)
+        losses = []
+        started_next = next_group is None
+        for k in range(steps):
+            self._stage_group_rows(b, group, grp, k, B)
+            if self.temporal_net is not None:
+                self.temporal_net.align_batch(b["text"], b["visual"], out=b["temporal"])
+            else:
+                b["temporal"].copy_(group["temporal_features"][k * B:(k + 1) * B])
+            if not started_next and self.reducer.active:      # (before the collectives: see _train_step_pipelined)
+                self.prefetch_features(next_group, gslot ^ 1, inputs_ready, group=True)
+                started_next = True
+            self._fwd_bwd(b, B)
+            if not started_next:
+                self.prefetch_features(next_group, gslot ^ 1, inputs_ready, group=True)
+                started_next = True
+            self.reducer.finish()
+            self.optim.clip_and_step()
+            losses.append(self.optim.state.float_view("loss").clone())
+        done = torch.cuda.Event()
+        done.record(main)
+        self._grp_free[gslot] = done
+        self._mark("opt1", main)
+        self._gslot ^= 1
+        return {"loss": self.optim.state.float_view("loss"), "losses": losses, "probs": b["probs"], "y": b["label"],
+                "forensic": b["forensic"], "logits": b["logits"]}
+
+    def _stage_group_rows(self, b: dict, group, grp: dict, k: int, B: int) -> None:
+        """Rows [kB, (k+1)B) of the group's features and small inputs into the step's static buffers: ONE gather launch."""
+        pairs = [(grp["text"], b["text"]), (grp["visual"], b["visual"]), (group["audio_features"], b["audio"]), (group["aux"], b["aux"]),
+                 (group["label"], b["label"]), (group["gnn_feat"], b["gnn"])]
+        for src, dst in pairs:
+            if not (src.device == dst.device and src.dtype == dst.dtype and src.is_contiguous() and tuple(src.shape[1:]) == tuple(dst.shape[1:]) and
+                    (src[0].numel() * src.element_size()) % 8 == 0):
+                raise RuntimeError(f"lookahead group tensor {tuple(src.shape)} {src.dtype} does not match its step buffer {tuple(dst.shape)} {dst.dtype}")
+        if self._iota is None or self._iota.numel() < B:
+            self._iota = torch.arange(max(B, 256), dtype=torch.int64, device=self.device)
+        items = (L.GatherItem * len(pairs))()
+        for it, (src, dst) in zip(items, pairs):
+            rb = src[0].numel() * src.element_size()
+            it.src, it.dst, it.row_bytes, it.src_rows = src.data_ptr() + k * B * rb, dst.data_ptr(), rb, B
+        L.check(L.lib().ufnd_gather_rows(self._iota.data_ptr(), B, items, len(pairs), L.stream_ptr(self.device)), "ufnd_gather_rows")
 
     def _stage_small_inputs(self, b: dict, batch, B: int) -> None:
         """audio / aux / label / gnn rows of a raw batch into the step's static buffers: ONE ufnd_gather_rows launch (identity
