@@ -28,13 +28,14 @@ for r in rows:
     key = (short(r["Kernel_Name"]), int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), r["Grid_Size_Y"], r["Grid_Size_Z"])
     agg[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 gem = [r for r in rows if "gemm_bf16" in r["Kernel_Name"]]
-n_inst = 3 * j["roofline"]["launches_per_step"]
+n_inst = 3 * j["roofline"].get("launches_per_encoder_pass", j["roofline"].get("launches_per_step"))
 pl = j["roofline"]["per_launch"]
 inst = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in gem[-n_inst:]]
 over = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in gem[:-n_inst]]
 with open(f"profiles/{tag}_summary.md", "w") as f:
     f.write(f"# {tag}\n\nCommand (GPU box, 1x MI355X): `cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv "
-            f"-d gpurun_out/prof -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --repeats 1`\n\n")
+            f"-d gpurun_out/prof -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-lookahead-compare --repeats 1` "
+            f"(default encoder lookahead: {j['config'].get('encoder_lookahead_batches', 1)} batches per encoder pass)\n\n")
     roc = sum(inst) / len(inst) / 1e3
     f.write(f"bench line UNDER THE PROFILER (the profiler slows the step by about a third; never compare it with an unprofiled run): "
             f"**{j['value']} samples/s, {j['ms_per_step']} ms/step**, whole-step `roofline.frac` {j['roofline']['frac']}.\n\n")
@@ -52,7 +53,9 @@ with open(f"profiles/{tag}_summary.md", "w") as f:
         up = u["roofline"]["per_launch"]
         f.write(f"The same command WITHOUT the profiler, same box, minutes earlier (`profiles/{tag}_unprofiled.json`): **{u['value']} samples/s, "
                 f"{u['ms_per_step']} ms/step** (blocks {u['timing']['ms_per_step_blocks']}), whole-step frac **{u['roofline']['frac']}**, per-launch "
-                f"{up['avg_launch_us']} us = {up['achieved']} TFLOP/s ({up['frac']}).\n\n")
+                f"{up['avg_launch_us']} us = {up['achieved']} TFLOP/s ({up['frac']})"
+                + (f"; the same optimizer steps with one batch per encoder pass, same process: {u['lookahead_1']['value']} samples/s, {u['lookahead_1']['ms_per_step']} ms/step"
+                   if u.get("lookahead_1") else "") + ".\n\n")
         shutil.copy(unprofiled, f"profiles/{tag}_unprofiled.json")
     f.write("Per shape (HIP events, this profiled run): " + json.dumps(pl["by_shape_MxNxK"]) + "\n\n")
     f.write("| kernel | blocks (x,y,z) | launches | median us | min us | total ms |\n|---|---|---|---|---|---|\n")
