@@ -11,6 +11,10 @@ full model, batch 32 per GPU, seq_len 128, one 224x224 frame), inputs resident i
   DeepTruthClassifier fwd (train-mode dropout) -> CE ->
   backward -> [RCCL all-reduce] -> clip_grad_norm_(5) -> AdamW.   (encoders frozen, as in the
   reference; nothing is cached or skipped inside the timed region.)
+Encoder lookahead (--lookahead G, default 4): the frozen encoders run over G consecutive batches per pass -- every batch is
+encoded exactly once, inside the timed region, with features bit-identical to one-batch passes -- while the head, the loss,
+the exchange, the clip and AdamW step batch by batch (32 samples per optimizer step).  The line's `lookahead_1` field is the
+same run's throughput with one batch per encoder pass.
 Prints ONE JSON line (rank 0) with the contract's fields plus `roofline` (the bf16 GEMM kernel,
 timed with HIP events on its stream) and `cpu_baseline` (the oracle's same step on host cores,
 bounded sample).
