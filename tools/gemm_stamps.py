@@ -5,7 +5,8 @@ configuration and shape, the median over blocks of each phase in us (100 MHz rea
 shader clock held inside the K loop, and the first-start -> last-end span of the whole grid.
 With --ln every tile that has a LayerNorm-aware kernel is also stamped in its two roles: "fold" (LayerNorm of
 the A operand folded in) and "rln" (residual through a LayerNorm + bf16 copy + row statistics out).
-usage: gemm_stamps.py [--cfgs=8,22] [--shapes=bert_qkv,bert_ffn1] [--ln]"""
+--mscale=G: G times the rows (the launches of an encoder pass over G batches).
+usage: gemm_stamps.py [--cfgs=8,22] [--shapes=bert_qkv,bert_ffn1] [--ln] [--mscale=4]"""
 import sys
 from pathlib import Path
 
@@ -26,9 +27,11 @@ def main():
         if a.startswith("--shapes="):
             want = a.split("=")[1].split(",")
     dev = "cuda"
+    mscale = max([int(a.split("=")[1]) for a in sys.argv if a.startswith("--mscale=")] + [1])
     for name, M, N, K in SHAPES:
         if want and name not in want:
             continue
+        M *= mscale
         g = torch.Generator().manual_seed(M + N)
         A = torch.randn(M, K, generator=g).to(dev).bfloat16()
         W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).bfloat16()

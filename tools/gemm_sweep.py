@@ -26,7 +26,7 @@ TILES = {0: (128, 128, "2x2/3,3"), 1: (128, 64, "2x2/3,3"), 2: (256, 128, "4x2/3
          20: (128, 64, "4x2/4,4"), 21: (256, 192, "2x4/2,2"), 22: (256, 192, "4x2/3,2"), 23: (256, 256, "4x2/3,2"),
          24: (128, 192, "4x2/4,4"), 25: (128, 256, "4x2/3,3"),
          # 32x32x16 MFMA forms
-         26: (256, 192, "4x2/2,2/m32"), 27: (128, 128, "4x2/3,3/m32"), 28: (256, 144, "8x1/2,2")}
+         26: (256, 192, "4x2/2,2/m32"), 27: (128, 128, "4x2/3,3/m32"), 28: (256, 144, "8x1/2,2"), 29: (128, 128, "4x2/2,2")}
 
 
 REAL = {}   # name -> (act, use_residual_and_f32_out): the epilogue each shape has in the encoders

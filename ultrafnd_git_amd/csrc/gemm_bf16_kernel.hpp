@@ -106,8 +106,16 @@ template <int V> struct IntC { static constexpr int value = V; };
 //          S^T = K Q^T, online softmax over two 64-key blocks, O^T = V^T P^T.  Same operations in the same order as
 //          ufnd_gemm_bf16[_ln] + ufnd_attention_bf16: bit-identical ctx, without the (tokens, 3H) round trip through
 //          HBM, the second launch and its three dependent memory round trips.
+// waves per SIMD the register allocation must leave room for: tiles whose LDS footprint lets two workgroups share a CU
+// (<= 80 KiB) only do so if two workgroups' waves also fit the register file (8-wave blocks: 128 registers per lane)
+constexpr int gemm_waves_per_simd(int BM, int BN, int WM, int WN, int STA, int STB, int MI, int LNX, int ATT) {
+  const int ring = (STA * BM + STB * BN) * 128, cbytes = WM * WN * MI * (BN / WN + 4) * 4;
+  const int smem = (ring > cbytes ? ring : cbytes) + (LNX ? BM * 8 : 0);
+  return (!ATT && smem <= 80 * 1024 ? 2 : 1) * WM * WN / 4;
+}
 template <int BM, int BN, int WM, int WN, int STA, int STB, int MI, int ABL = 0, int DBG = 0, int LNX = 0, int ATT = 0>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(gemm_waves_per_simd(BM, BN, WM, WN, STA, STB, MI, LNX, ATT))))
+void gemm_bf16_kernel(const GemmArgs a) {
   static_assert(MI == 16 || MI == 32, "MFMA shape");
   static_assert(!ATT || (BM == 128 && BN == 384 && MI == 16 && WM * WN == 8 && LNX == 1), "fused attention tile");
   using acc_t = typename std::conditional<MI == 16, f32x4, f32x16>::type;
@@ -473,7 +481,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     constexpr bool FOLD = LNX && decltype(mode_)::value == 1, RLN = LNX && decltype(mode_)::value == 2;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      // the residual rows of this patch are requested first: they land while the patch is staged
+      // the residual rows of this patch are requested first: they land while the patch is staged.  (Requesting them one
+      // patch ahead into a second register set changes nothing -- 15.9 us either way for a 256x192 tile at 16,384 rows:
+      // that epilogue moves 490 KB per CU on all 256 CUs at once = 7.8 TB/s, it is bound by the fabric, not by latency.)
       float rr8[NIT][8];
       if (a.residual) {
 #pragma unroll
@@ -726,7 +736,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
   X(0, 128, 128, 2, 2, 3, 3, 16, 0, 0)   /*  96 KiB */                                                           \
   X(1, 128, 64, 2, 2, 3, 3, 16, 0, 0)    /*  72 KiB (2 blocks/CU) */                                             \
   X(2, 256, 128, 4, 2, 3, 3, 16, 1, 1)   /* 144 KiB */                                                           \
-  X(3, 128, 128, 2, 2, 2, 2, 16, 0, 0)   /*  64 KiB (2 blocks/CU) */                                             \
+  X(3, 128, 128, 2, 2, 2, 2, 16, 1, 0)   /*  64 KiB (2 blocks/CU) */                                             \
   X(4, 128, 64, 2, 2, 4, 4, 16, 0, 0)    /*  96 KiB */                                                           \
   X(5, 256, 64, 4, 2, 3, 3, 16, 0, 0)    /* 120 KiB */                                                           \
   X(6, 128, 288, 2, 2, 3, 3, 16, 0, 0)   /* 156 KiB (N=2304 -> 8 column tiles) */                                \
@@ -751,7 +761,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
   X(25, 128, 256, 4, 2, 3, 3, 16, 0, 0)  /* 144 KiB (8 waves, wave tile 32x128) */                               \
   X(26, 256, 192, 4, 2, 2, 2, 32, 0, 0)  /* 32x32x16 MFMA form (measured 2-4 % slower than 16x16x32 on every shape) */ \
   X(27, 128, 128, 4, 2, 3, 3, 32, 0, 0)                                                                    \
-  X(28, 256, 144, 8, 1, 2, 2, 16, 1, 1)  /* 100 KiB: N=2304 -> 16 x 16 = 256 tiles (wave tile 32x144; W pieces dealt unevenly) */
+  X(28, 256, 144, 8, 1, 2, 2, 16, 1, 1)  /* 100 KiB: N=2304 -> 16 x 16 = 256 tiles (wave tile 32x144; W pieces dealt unevenly) */ \
+  X(29, 128, 128, 4, 2, 2, 2, 16, 1, 0)  /*  64 KiB, 8 waves (wave tile 32x64, 110 registers): 2 blocks/CU (measured: no gain) */
 
 #ifdef UFND_DIAG
 #define UFND_TILE_BUILT(PROD_) 1
