@@ -52,6 +52,9 @@ def main():
                 variants.append((c, bm, bn, lay + " fold", "fold"))
                 if N // 32 <= 24 and (bn // 2) % 32 == 0:
                     variants.append((c, bm, bn, lay + " rln", "rln"))
+                    if "--ablate-rln" in sys.argv:     # the residual epilogue piece by piece
+                        for m in ("res0", "res", "res+stats", "rln-nostats"):
+                            variants.append((c, bm, bn, lay + " " + m, m))
         for c, bm, bn, lay, mode in variants:
             nblk = -(-M // bm) * (N // bn)
             st = torch.zeros(nblk, 8, dtype=torch.int64, device=dev)
@@ -63,12 +66,18 @@ def main():
                 ln.width = 768
                 if mode == "fold":
                     ln.a_stats, ln.colsum, ln.a_parts = stats.data_ptr(), vec.data_ptr(), 24
-                else:
+                elif mode == "rln":
                     ln.r_stats, ln.r_gamma, ln.r_beta, ln.r_parts, ln.out_stats = stats.data_ptr(), vec.data_ptr(), vec.data_ptr(), 24, sto.data_ptr()
+                elif mode == "rln-nostats":
+                    ln.r_stats, ln.r_gamma, ln.r_beta, ln.r_parts = stats.data_ptr(), vec.data_ptr(), vec.data_ptr(), 24
+                elif mode == "res+stats":      # plain fp32 residual, fp32 + bf16 out, statistics out
+                    ln.out_stats = sto.data_ptr()
+                elif mode == "res0":           # the plain kernel: fp32 residual, fp32 + bf16 out
+                    ln = None
             for it in range(12):
                 dcheck(diag().ufnd_diag_gemm_bf16_stamps(A.data_ptr(), W.data_ptr(), ob.data_ptr(), M, N, K, c, st.data_ptr(),
-                                                      ctypes.byref(ln) if ln is not None else None, vec.data_ptr() if ln is not None else None,
-                                                      res.data_ptr() if mode == "rln" else None, of.data_ptr() if mode == "rln" else None,
+                                                      ctypes.byref(ln) if ln is not None else None, vec.data_ptr() if mode is not None else None,
+                                                      res.data_ptr() if mode not in (None, "fold") else None, of.data_ptr() if mode not in (None, "fold") else None,
                                                       L.stream_ptr(A.device)), "stamps")
                 torch.cuda.synchronize()
                 if it >= 4:

@@ -2,7 +2,7 @@
 """Sweep the tile configurations of the bf16 GEMM (diagnostics library: every tile, ablations) over the encoder GEMM shapes (GPU box).
 Interleaved rounds in ONE process (variants x rounds), median of per-launch HIP-event times minus
 the empty event-pair time, random operands.  Every variant is first checked against an fp32 torch
-matmul of the same bf16 data.   usage: gemm_sweep.py [rounds] [--ablate] [--real] [--cold] [--cfgs=8,22] [--shapes=bert_qkv,...]"""
+matmul of the same bf16 data.   usage: gemm_sweep.py [rounds] [--ablate] [--real] [--cold] [--mscale=4] [--cfgs=8,22] [--shapes=bert_qkv,...]"""
 import json
 import sys
 from pathlib import Path
@@ -118,7 +118,12 @@ def main():
         if a.startswith("--shapes="):
             want = a.split("=")[1].split(",")
             shapes = [s for s in SHAPES if s[0] in want]
+    mscale = max([int(a.split("=")[1]) for a in sys.argv if a.startswith("--mscale=")] + [1])   # G x the rows (encoder lookahead G)
+    if mscale > 1:
+        ST, STO = ST.repeat(mscale, 1, 1), STO.repeat(mscale, 1, 1)
+        RES, OF = torch.randn(4096 * mscale, 3072, device=DEV), torch.empty(4096 * mscale, 3072, device=DEV)
     for name, M, N, K in shapes:
+        M *= mscale
         g = torch.Generator().manual_seed(M + N)
         A = torch.randn(M, K, generator=g).to(DEV).bfloat16()
         W = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV).bfloat16()
