@@ -289,3 +289,32 @@ def test_encoder_lookahead_groups_equal_plain_steps(tmp_path):
         outs.append((out["logits"].clone(), tr.arena.data.clone(), losses, int(tr.optim.state.read().step)))
     assert outs[0][3] == outs[1][3] == 5 and outs[0][2] == outs[1][2]
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_epoch_loop_with_encoder_lookahead_equals_the_plain_epoch_loop(tmp_path):
+    """fit()'s training epochs with the encoders inside the step: encoder_lookahead = 3 (groups of 3 batches per encoder pass, a
+    shorter tail group, the ragged last batch as a plain step) against encoder_lookahead = 1 (one train_step per batch): the same
+    batches in the same order -- epoch losses, epoch metrics and the whole parameter arena are bit-identical after two epochs."""
+    from oracle import encoders_ref as E
+    from ultrafnd_git_amd.encoders import BertTextEncoder, ClipVisualEncoder
+    from ultrafnd_git_amd.trainer import ForensicTrainer, TrainConfig, synthetic_cache
+    tenc, venc = BertTextEncoder(layers=2, vocab_size=500), ClipVisualEncoder(layers=1)
+    tenc.load_state_dict(E.seeded_weights(E.bert_shapes(layers=2, vocab=500), 11))
+    venc.load_state_dict(E.seeded_weights(E.vit_shapes(layers=1), 12))
+    tenc, venc = tenc.to(DEV), venc.to(DEV)
+    cache = synthetic_cache(48, seed=2, with_raw=True, seq_len=128, vocab=500)      # train split: 33 rows = 8 batches of 4 + 1 row
+    res = []
+    for la in (1, 3):
+        torch.manual_seed(5)
+        cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir=str(tmp_path / f"la{la}"), batch_size=4, epochs=2, device=DEV,
+                          encode_inline=True, encoder_lookahead=la)
+        tr = ForensicTrainer(cfg, cache=cache, text_encoder=tenc, visual_encoder=venc)
+        ep = [tr._epoch_loop(tr.train_loader, "train") for _ in range(2)]
+        torch.cuda.synchronize()
+        res.append((ep, tr.arena.data.clone(), int(tr.optim.state.read().step)))
+        if la == 3:
+            assert sorted(k[0] for k in tr._grp_in) == [8, 8, 12, 12]            # groups of 3 and 2 batches, two slots each
+    assert res[0][2] == res[1][2] == 18
+    for (l0, m0), (l1, m1) in zip(res[0][0], res[1][0]):
+        assert l0 == l1 and m0 == m1
+    assert torch.equal(res[0][1], res[1][1])

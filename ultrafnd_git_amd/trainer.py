@@ -77,6 +77,9 @@ class TrainConfig:
     # the integrated variant's in-graph GNN (forensic_trainer_integrated.py:132-138,203-224): gnn_feat of a mini-batch comes from
     # a GNNModel over the batch's own OCR-Jaccard graph and is trained WITH the head (the main trainer's gnn_feat is a detached table)
     gnn_in_graph: bool = False
+    # encode_inline: the frozen encoders run over this many consecutive batches per pass (train_group_pipelined); the head,
+    # the exchange and the optimizer still step batch by batch, bit-identical to one batch per pass.  1 = off.
+    encoder_lookahead: int = 4
 
 
 class CachedTensorDataset(torch.utils.data.Dataset):
@@ -299,6 +302,7 @@ class ForensicTrainer:
         self._slot_free = [None, None]
         self._gslot = 0                      # encoder lookahead (train_group_pipelined): group feature buffers, two slots
         self._grp_bufs: Dict[Tuple[int, int], dict] = {}
+        self._grp_in: Dict[Tuple[int, int], dict] = {}     # persistent input buffers of the epoch loop's lookahead groups
         self._grp_ready = [None, None]
         self._grp_free = [None, None]
 
@@ -660,23 +664,25 @@ class ForensicTrainer:
         return self._grp_bufs[key]
 
     def train_group_pipelined(self, group: Dict[str, torch.Tensor], next_group: Optional[Dict[str, torch.Tensor]],
-                              steps: Optional[int] = None) -> dict:
+                              steps: Optional[int] = None, on_step=None) -> dict:
         """`steps` (default: all G) optimizer steps over a lookahead group: a dict of raw inputs with G x batch_size rows whose
         features prefetch_features(group=True) has started.  The encoders are frozen (as in the reference, where the features
         are a precomputed cache), so encoding G batches in ONE pass changes no value -- a row's features do not depend on the
         batch it is encoded in, bit for bit (test) -- while every GEMM launch gets G times the rows: fewer, larger launches.
         The head, the loss, the gradient exchange, the clip and AdamW run per batch of batch_size rows, in order, exactly as
-        train_step does: G optimizer steps.  The next group's encoders are enqueued behind the first head."""
+        train_step does: G optimizer steps.  The next group's encoders are enqueued behind the first head.
+        `on_step(b)` (optional) is called after every optimizer step with the step's static buffers (the epoch loop clones
+        what its metrics need)."""
         if self._hp_stream is None:
             self._hp_stream = torch.cuda.Stream(device=self.device, priority=-1)
         caller = torch.cuda.current_stream(self.device)
         self._hp_stream.wait_stream(caller)
         with torch.cuda.stream(self._hp_stream):
-            out = self._train_group_pipelined(group, next_group, steps)
+            out = self._train_group_pipelined(group, next_group, steps, on_step)
         caller.wait_stream(self._hp_stream)
         return out
 
-    def _train_group_pipelined(self, group, next_group, steps) -> dict:
+    def _train_group_pipelined(self, group, next_group, steps, on_step=None) -> dict:
         B = int(self.cfg.batch_size)
         GB = int(group["input_ids"].shape[0])
         if GB % B:
@@ -714,6 +720,8 @@ class ForensicTrainer:
             self.reducer.finish()
             self.optim.clip_and_step()
             losses.append(self.optim.state.float_view("loss").clone())
+            if on_step is not None:
+                on_step(b)
         done = torch.cuda.Event()
         done.record(main)
         self._grp_free[gslot] = done
@@ -897,7 +905,17 @@ class ForensicTrainer:
         ys: List[torch.Tensor] = []
         p1s: List[torch.Tensor] = []
         fors: List[torch.Tensor] = []
-        for batch in loader:
+        lookahead = (is_train and self.cfg.encode_inline and int(self.cfg.encoder_lookahead) > 1 and self.cfg.use_graph and
+                     self.gnn_model is None and isinstance(loader, DeviceBatchLoader) and loader.dataset.ids_tok is not None and
+                     loader.dataset.frames is not None and loader.dataset.G is not None)
+        if lookahead:
+            def sink(b):
+                losses.append(self.optim.state.float_view("loss").clone())
+                ys.append(b["label"].clone())
+                p1s.append(b["probs"][:, 1].clone())
+                fors.append(b["forensic"].clone())
+            self._train_epoch_lookahead(loader, sink)
+        for batch in (() if lookahead else loader):
             if is_train:
                 out = self.train_step(batch, split)
                 f = out["forensic"]
@@ -940,6 +958,49 @@ class ForensicTrainer:
         metrics = aggregate_epoch_metrics(y_true=y_cat.cpu().numpy(), y_score=p1_cat.cpu().numpy().astype(float),
                                           forensic=forensic, threshold=0.5, include_cm=False)
         return loss_mean, metrics
+
+    def _group_inputs(self, ds: CachedTensorDataset, rows: torch.Tensor, slot: int) -> dict:
+        """Raw inputs and small per-sample inputs of a lookahead group, gathered into PERSISTENT buffers (one set per group
+        size and slot): the encoder graphs are captured per input address, so a group's inputs must not move."""
+        n = int(rows.numel())
+        key = (n, slot)
+        src = {"input_ids": ds.ids_tok, "attention_mask": ds.mask_tok, "frames": ds.frames, "audio_features": ds.A, "aux": ds.AUX,
+               "label": ds.y, "gnn_feat": ds.G, "temporal_features": ds.U}
+        buf = self._grp_in.get(key)
+        if buf is None:
+            buf = self._grp_in[key] = {k: torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=self.device) for k, t in src.items()}
+        for k, t in src.items():
+            torch.index_select(t, 0, rows, out=buf[k])
+        out = dict(buf)
+        out["index"] = rows
+        return out
+
+    def _train_epoch_lookahead(self, loader: "DeviceBatchLoader", sink) -> None:
+        """One training epoch over a device-resident split of RAW inputs with the encoders inside the step: the loader's
+        (sharded, shuffled) index list is cut into groups of encoder_lookahead batches -- the frozen encoders run once per
+        group, the optimizer steps batch by batch (train_group_pipelined) -- then a shorter group of the remaining whole
+        batches, then the ragged last batch (drop_last=False) as a plain train_step.  Same batches in the same order, same
+        parameter updates as the plain loop, bit for bit (test)."""
+        G, B, ds = int(self.cfg.encoder_lookahead), int(self.cfg.batch_size), loader.dataset
+        idx = loader._indices().to(self.device)
+        loader.epoch += 1
+        n = int(idx.numel())
+        cuts, s = [], 0
+        while n - s >= B:
+            g = min(G, (n - s) // B)
+            cuts.append((s, s + g * B))
+            s += g * B
+        cur = None
+        for i, (lo, hi) in enumerate(cuts):
+            if cur is None:
+                cur = self._group_inputs(ds, idx[lo:hi], self._gslot)
+                self.prefetch_features(cur, group=True)
+            nxt = self._group_inputs(ds, idx[cuts[i + 1][0]:cuts[i + 1][1]], self._gslot ^ 1) if i + 1 < len(cuts) else None
+            self.train_group_pipelined(cur, nxt, on_step=sink)
+            cur = nxt
+        if s < n:
+            out = self.train_step(IndexedBatch(ds, idx[s:]), "train")
+            sink({"label": out["y"], "probs": out["probs"], "forensic": out["forensic"]})
 
     # ------------------------------------------------------------------ fit / test (forensic_trainer.py:332-396)
     def fit(self):
