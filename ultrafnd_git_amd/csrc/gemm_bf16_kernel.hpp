@@ -860,6 +860,9 @@ static int auto_cfg(int M, int N, int K) {
     if (N % 192 == 0 && N >= 3072) return 17;          //   128x192
     if (N % 128 == 0) return 16;                       //   128x128
   }
+  // narrow N with 128x192 tiles filling ONE round (ViT out-proj / FFN2 at 6,400 rows = encoder lookahead 4: 200 tiles instead of
+  // 300 tiles of 128x128 in 1.17 rounds -- FFN2 55 -> 44 us, out-proj 22 -> 18.5 us, step +0.9 % in three interleaved pairs of runs)
+  if (N < 2048 && N % 192 == 0 && tiles(17) >= 150 && tiles(17) <= 256) return 17;
   if (N % 128 == 0 && tiles(16) >= 150) return 16;     // narrow N at M=4096 (attention out-proj, output.dense): 128x128
   return 20;                                           // small problems (ViT out-proj / FFN2 / patch embedding): 128x64, 4-slot ring
 }
