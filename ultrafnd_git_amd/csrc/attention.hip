@@ -24,7 +24,7 @@
 
 namespace {
 
-constexpr int QB = 128;          // queries per workgroup
+constexpr int QB = 128;          // queries per workgroup (4 waves x 32; the short-sequence form: 2 waves, 64 queries)
 constexpr float NEG_MASK = -3.0e38f;
 
 __device__ __forceinline__ bf16x8 k_frag(const char* tile, int row, int chunk) {
@@ -32,8 +32,11 @@ __device__ __forceinline__ bf16x8 k_frag(const char* tile, int row, int chunk) {
 }
 
 // KB = keys per block (64: ~216 registers -> two workgroups per CU; 128: fewer softmax rescales)
-template <int KB>
-__global__ __launch_bounds__(256) void attention_kernel(const __bf16* qkv, const int32_t* mask, __bf16* ctx, int L,
+// NW = waves per workgroup (32 queries each).  Sequences of <= 64 tokens (ViT-B/32: 50) run with NW = 2: the 4-wave form spends
+// half its waves on clamped duplicate queries there, and its 216 registers allow 8 waves per CU either way -- twice the
+// samples in flight with 2-wave workgroups (a block is one dependent chain: loads -> S -> softmax -> O -> store).
+template <int KB, int NW = 4>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 2 ? 3 : 2))) void attention_kernel(const __bf16* qkv, const int32_t* mask, __bf16* ctx, int L,
                                                         int heads, float scale_log2e, const int32_t* cu) {
   __shared__ __attribute__((aligned(16))) char ks[KB * 128];
   __shared__ __attribute__((aligned(16))) char vs[KB * 128];
@@ -46,7 +49,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const __bf16* qkv, const
   if (cu) {              // packed (un-padded) sequences: rows cu[b] .. cu[b+1], every key valid
     tok0 = (size_t)cu[b];
     L = cu[b + 1] - cu[b];
-    if (qb * QB >= L) return;      // (block-uniform, before any barrier)
+    if (qb * (NW * 32) >= L) return;      // (block-uniform, before any barrier)
   }
 
   // Q fragments (B operand): lane (query fr, g) holds Q[query][8g + 32kk .. +7]
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const __bf16* qkv, const
   int qrow[2];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
-    const int q = qb * QB + wave * 32 + qt * 16 + fr;
+    const int q = qb * (NW * 32) + wave * 32 + qt * 16 + fr;
     qrow[qt] = q;
     const int qc = q < L ? q : L - 1;
     const __bf16* src = qkv + (tok0 + qc) * ld + h * 64 + 8 * g;
@@ -73,8 +76,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const __bf16* qkv, const
     __syncthreads();  // previous block's LDS reads are done
     // ---- stage K and V tiles (row-major 128-B rows, swizzled 16-B chunks) and the key bias
 #pragma unroll
-    for (int it = 0; it < KB / 32; ++it) {
-      const int idx = tid + 256 * it, key = idx >> 3, c = idx & 7;
+    for (int it = 0; it < KB * 8 / (NW * 64); ++it) {
+      const int idx = tid + NW * 64 * it, key = idx >> 3, c = idx & 7;
       const int kr = (kb0 + key) < L ? (kb0 + key) : L - 1;
       const __bf16* src = qkv + (tok0 + kr) * ld + H + h * 64 + c * 8;
       const bf16x8 kv = *reinterpret_cast<const bf16x8*>(src);
@@ -191,8 +194,12 @@ extern "C" int ufnd_attention_bf16(const void* qkv, const int32_t* key_mask, voi
   UFND_REQUIRE(ufnd_aligned(qkv, 16) && ufnd_aligned(ctx, 16), "attention: 16-B alignment required");
   UFND_REQUIRE(B <= 65535, "attention: B too large for grid.z");
   const float scale_log2e = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) * log2(e)
-  hipLaunchKernelGGL(attention_kernel<64>, dim3(ufnd_cdiv(L, QB), heads, B), dim3(256), 0, (hipStream_t)stream_,
-                     (const __bf16*)qkv, key_mask, (__bf16*)ctx, L, heads, scale_log2e, (const int32_t*)nullptr);
+  if (L <= 64)
+    hipLaunchKernelGGL((attention_kernel<64, 2>), dim3(1, heads, B), dim3(128), 0, (hipStream_t)stream_,
+                       (const __bf16*)qkv, key_mask, (__bf16*)ctx, L, heads, scale_log2e, (const int32_t*)nullptr);
+  else
+    hipLaunchKernelGGL((attention_kernel<64, 4>), dim3(ufnd_cdiv(L, QB), heads, B), dim3(256), 0, (hipStream_t)stream_,
+                       (const __bf16*)qkv, key_mask, (__bf16*)ctx, L, heads, scale_log2e, (const int32_t*)nullptr);
   UFND_CHECK_LAUNCH();
   return UFND_OK;
 }
@@ -204,7 +211,7 @@ extern "C" int ufnd_attention_bf16_varlen(const void* qkv, const int32_t* cu_seq
                B, max_len, heads);
   UFND_REQUIRE(ufnd_aligned(qkv, 16) && ufnd_aligned(ctx, 16), "attention_varlen: 16-B alignment required");
   const float scale_log2e = 0.125f * 1.44269504088896340736f;
-  hipLaunchKernelGGL(attention_kernel<64>, dim3(ufnd_cdiv(max_len, QB), heads, B), dim3(256), 0, (hipStream_t)stream_,
+  hipLaunchKernelGGL((attention_kernel<64, 4>), dim3(ufnd_cdiv(max_len, QB), heads, B), dim3(256), 0, (hipStream_t)stream_,
                      (const __bf16*)qkv, (const int32_t*)nullptr, (__bf16*)ctx, max_len, heads, scale_log2e, cu_seqlens);
   UFND_CHECK_LAUNCH();
   return UFND_OK;
