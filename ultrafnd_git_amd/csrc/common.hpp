@@ -76,6 +76,34 @@ __device__ __forceinline__ float gelu_fast_f(float x) {
   return __fmaf_rn(h, copysignf(erf_abs, x), h);
 }
 
+// Two elements at a time on the packed fp32 pipe (v_pk_mul_f32 / v_pk_fma_f32: one issue slot for two lanes' worth of
+// IEEE operations -- the same roundings as the scalar forms above, element for element, so results are bit-identical; the
+// reciprocal and the exponential stay scalar).  The GELU epilogue of a 256x192 FFN1 tile is ~6 us of vector issue.
+__device__ __forceinline__ f32x2 gelu_fast_f2(f32x2 x) {
+#pragma clang fp contract(off)
+  const f32x2 z = __builtin_elementwise_abs(x) * 0.70710678118654752440f;
+  const f32x2 u = __builtin_elementwise_fma(f32x2{0.3275911f, 0.3275911f}, z, f32x2{1.0f, 1.0f});
+  const f32x2 t = {__builtin_amdgcn_rcpf(u.x), __builtin_amdgcn_rcpf(u.y)};
+  f32x2 p = __builtin_elementwise_fma(t, f32x2{1.061405429f, 1.061405429f}, f32x2{-1.453152027f, -1.453152027f});
+  p = __builtin_elementwise_fma(t, p, f32x2{1.421413741f, 1.421413741f});
+  p = __builtin_elementwise_fma(t, p, f32x2{-0.284496736f, -0.284496736f});
+  p = __builtin_elementwise_fma(t, p, f32x2{0.254829592f, 0.254829592f});
+  const f32x2 poly = t * p;
+  const f32x2 zz = (-z) * z;
+  const f32x2 e = {__expf(zz.x), __expf(zz.y)};
+  const f32x2 erf_abs = __builtin_elementwise_fma(-poly, e, f32x2{1.0f, 1.0f});
+  const f32x2 h = x * 0.5f;
+  const f32x2 sg = {copysignf(erf_abs.x, x.x), copysignf(erf_abs.y, x.y)};
+  return __builtin_elementwise_fma(h, sg, h);
+}
+__device__ __forceinline__ f32x2 quick_gelu_fast_f2(f32x2 x) {
+#pragma clang fp contract(off)
+  const f32x2 m = x * 1.702f;
+  const f32x2 d = f32x2{__expf(-m.x), __expf(-m.y)} + 1.0f;
+  const f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  return x * r;
+}
+
 // butterfly partner inside a quad (lanes 4k..4k+3) by DPP quad_perm: no LDS round trip (a __shfl_xor compiles to
 // ds_bpermute, ~100 cycles of dependent latency each)
 __device__ __forceinline__ float quad_xor1(float v) {       // lane ^ 1: quad_perm [1,0,3,2]

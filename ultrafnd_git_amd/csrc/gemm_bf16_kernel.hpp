@@ -69,6 +69,10 @@ __device__ __forceinline__ float opaque_f(float x) {
   asm volatile("" : "+v"(x));
   return x;
 }
+__device__ __forceinline__ f32x2 opaque_f2(f32x2 x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
 
 __device__ __forceinline__ bf16x8 lds_frag(const char* tile, int row, int chunk) {
   return *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
@@ -496,25 +500,31 @@ void gemm_bf16_kernel(const GemmArgs a) {
           }
         }
       }
-      // register phase: [folded LayerNorm of the A operand,] bias, activation on the accumulators where they lie
+      // register phase: [folded LayerNorm of the A operand,] bias, activation on the accumulators where they lie, two rows
+      // (adjacent accumulator registers) per packed fp32 operation
 #pragma unroll
-      for (int r = 0; r < AR; ++r) {
-        // accumulator register r of lane (fr, g): 16x16 -> row 4g + r; 32x32 -> row 8(r>>2) + 4g + (r&3)
+      for (int r = 0; r < AR; r += 2) {
+        // accumulator register r of lane (fr, g): 16x16 -> row 4g + r; 32x32 -> row 8(r>>2) + 4g + (r&3); r + 1 is the next row
         const int prow_ = MI == 16 ? 4 * g + r : 8 * (r >> 2) + 4 * g + (r & 3);
-        f32x2 ms = {0.f, 1.f};
-        if constexpr (FOLD) ms = st_lds[wm * TM + i * MI + prow_];      // {mean, rstd} of the row
+        f32x2 mean2 = {0.f, 0.f}, rstd2 = {1.f, 1.f};
+        if constexpr (FOLD) {      // {mean, rstd} of the two rows
+          const f32x2 a0 = st_lds[wm * TM + i * MI + prow_], a1 = st_lds[wm * TM + i * MI + prow_ + 1];
+          mean2 = f32x2{a0[0], a1[0]};
+          rstd2 = f32x2{a0[1], a1[1]};
+        }
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          float v = acc[i][j][r];
+          f32x2 v = {acc[i][j][r], acc[i][j][r + 1]};
           // LayerNorm(A) W'^T = rstd (A W'^T - mean colsum(W')); explicit roundings: every tile shape must
           // emit the same operation sequence (rows stay batch-invariant)
           // (opaque(): the product must not be re-fused with the bias add below -- the backend did so
           //  for a few elements of some tile shapes even with contraction switched off in the source)
-          if constexpr (FOLD) v = opaque_f(__fmul_rn(ms[1], __fmaf_rn(-ms[0], csj[j], v)));
-          v = __fadd_rn(v, bj[j]);
-          if constexpr (ACT == UFND_ACT_GELU) v = gelu_fast_f(v);
-          else if constexpr (ACT == UFND_ACT_QUICK_GELU) v = quick_gelu_fast_f(v);
-          cst[prow_ * CP + j * MI + fr] = v;
+          if constexpr (FOLD) v = opaque_f2(rstd2 * __builtin_elementwise_fma(-mean2, f32x2{csj[j], csj[j]}, v));
+          v = v + f32x2{bj[j], bj[j]};
+          if constexpr (ACT == UFND_ACT_GELU) v = gelu_fast_f2(v);
+          else if constexpr (ACT == UFND_ACT_QUICK_GELU) v = quick_gelu_fast_f2(v);
+          cst[prow_ * CP + j * MI + fr] = v.x;
+          cst[(prow_ + 1) * CP + j * MI + fr] = v.y;
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
