@@ -865,6 +865,10 @@ static int auto_cfg(int M, int N, int K) {
   // 256x192: BERT QKV (192 tiles) / FFN1 (256).  The A ring is 3 slots deep (tile 22, not 8): inside the encoder the
   // activation operand was just written by the previous kernel and comes from the Infinity Cache / HBM, not from L2
   // (gemm_sweep --rotate=40: 21.6 -> 19.4 us on QKV, 26.8 -> 24.7 on FFN1; cold WEIGHTS cost under 1 us either way)
+  // 256x256 where a wide-N launch has at least two full rounds of it (FFN1 at 16,384 rows = encoder lookahead 4: 768 tiles
+  // instead of 1024 of 256x192 -- the only tile whose K loop is not bound by the CU's operand ingest; 114 -> 108 us per launch,
+  // step +1.1 % in three interleaved pairs of runs.  Not for N = 2304: 9 column tiles, 64 vs 57 us alone.)
+  if (N % 256 == 0 && N >= 3072 && tiles(15) >= 512) return 15;
   if (N % 192 == 0 && tiles(22) >= 160) return 22;
   if (N >= 2048) {                                     // wide N, fewer rows (ViT QKV / FFN1): 32-row wave tiles
     if (N % 192 == 0 && N >= 3072) return 17;          //   128x192
