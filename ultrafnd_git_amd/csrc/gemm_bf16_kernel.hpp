@@ -869,6 +869,9 @@ static int auto_cfg(int M, int N, int K) {
   // instead of 1024 of 256x192 -- the only tile whose K loop is not bound by the CU's operand ingest; 114 -> 108 us per launch,
   // step +1.1 % in three interleaved pairs of runs.  Not for N = 2304: 9 column tiles, 64 vs 57 us alone.)
   if (N % 256 == 0 && N >= 3072 && tiles(15) >= 512) return 15;
+  // ... and where it fills ONE round (ViT QKV at 6,400 rows: 225 tiles instead of 300 of 256x192 in 1.17 rounds: 40 -> 29.5 us
+  // per launch, step +0.8 % in two interleaved pairs)
+  if (N % 256 == 0 && N >= 2048 && tiles(15) >= 190 && tiles(15) <= 256) return 15;
   if (N % 192 == 0 && tiles(22) >= 160) return 22;
   if (N >= 2048) {                                     // wide N, fewer rows (ViT QKV / FFN1): 32-row wave tiles
     if (N % 192 == 0 && N >= 3072) return 17;          //   128x192
