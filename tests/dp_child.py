@@ -91,6 +91,32 @@ def force1(out_dir):
         torch.cuda.synchronize()
         pipe[tag] = (tr.arena.data.clone(), out["logits"].clone())
     res["pipelined_bit_identical"] = bool(torch.equal(pipe["exchange"][0], pipe["plain"][0]) and torch.equal(pipe["exchange"][1], pipe["plain"][1]))
+    # encoder-lookahead groups (two batches per encoder pass) with the exchange live: the next group's encoders are enqueued
+    # before the first collective of the current one
+    grp = {}
+    for tag, active in (("exchange", True), ("plain", False)):
+        torch.manual_seed(7)
+        tenc, venc = BertTextEncoder(layers=2, vocab_size=500), ClipVisualEncoder(layers=2)
+        tenc.load_state_dict(wt); venc.load_state_dict(wv)
+        tenc, venc = tenc.to(DEV), venc.to(DEV)
+        cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir=out_dir, batch_size=8, device="cuda:0", use_graph=True, encode_inline=True)
+        tr = ForensicTrainer(cfg, cache=synthetic_cache(32, seed=1), text_encoder=tenc, visual_encoder=venc)
+        if not active:
+            tr.reducer.force = False
+        tr.fusion.train(); tr.clf.train()
+        groups = []
+        for k in range(2):
+            ids, mask = E.synthetic_tokens(50 + k, 16, 32, vocab=500, min_len=8)
+            d = dict_batches(16, 1, 60 + k)[0]
+            d.update({"input_ids": ids.to(DEV), "attention_mask": mask.to(torch.int32).to(DEV), "frames": E.synthetic_frames(70 + k, 16, 1).to(DEV)})
+            groups.append(d)
+        tr.prefetch_features(groups[0], group=True)
+        tr.train_group_pipelined(groups[0], groups[1])
+        out = tr.train_group_pipelined(groups[1], None)
+        torch.cuda.synchronize()
+        grp[tag] = (tr.arena.data.clone(), out["logits"].clone(), int(tr.optim.state.read().step))
+    res["lookahead_bit_identical"] = bool(torch.equal(grp["exchange"][0], grp["plain"][0]) and torch.equal(grp["exchange"][1], grp["plain"][1])
+                                          and grp["exchange"][2] == grp["plain"][2] == 4)
     res["backend"] = dist.get_backend()
     print(json.dumps(res))
     dist.destroy_process_group()

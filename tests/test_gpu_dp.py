@@ -33,7 +33,7 @@ def test_forced_rccl_exchange_on_one_rank_changes_no_bit(launch_job, tmp_path):
     and three pipelined steps leave the arena bit-identical to the same steps without any exchange."""
     res = _run(launch_job, 1, "force1", tmp_path, {"UFND_FORCE_REDUCE": "1"})
     assert res["backend"] == "nccl" and res["steps"] == 3
-    assert res["plain_steps_bit_identical"] and res["pipelined_bit_identical"], res
+    assert res["plain_steps_bit_identical"] and res["pipelined_bit_identical"] and res["lookahead_bit_identical"], res
 
 
 def test_two_ranks_on_one_gpu_equal_the_full_batch_step(launch_job, tmp_path):
