@@ -140,7 +140,7 @@ def cpu_baseline(B: int, slice_b: int = 8, warm: int = 3, timed: int = 20, budge
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1]: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
