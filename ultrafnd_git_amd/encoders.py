@@ -354,7 +354,7 @@ class BertTextEncoder(_EncoderBase):
             self._gemm_ln(b["h"], ly["w2"], ly["b2"], out_f32=y2, out_bf16=b["y2b"], residual=y1, r_stats=b["st1"],
                           r_gamma=ly["g1"], r_beta=ly["b1"], out_stats=b["st2"], eps=eps, which="ffn2")
             prev = ly
-        self._ln(y2, H, prev["g2"], prev["b2n"], b["xb"], b["xf"], M, H, eps)      # last_hidden_state is materialised once
+        self._ln(y2, H, prev["g2"], prev["b2n"], None, b["xf"], M, H, eps)           # last_hidden_state is materialised once (fp32 only: no GEMM reads it)
 
     @torch.no_grad()
     def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, unpad: bool = False, strict: bool = False) -> torch.Tensor:
