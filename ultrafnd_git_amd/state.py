@@ -3,7 +3,6 @@ dropout key and the step's scalar results live in HBM so that a captured hipGrap
 current values.  The host only touches it between epochs (lr) or to read results."""
 from __future__ import annotations
 
-import ctypes as C
 from typing import Dict
 
 import torch

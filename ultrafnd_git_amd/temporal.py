@@ -16,7 +16,6 @@ weights.  Forward only, like everything else in this module.  `delay_score` / `e
 reference's host-side helpers, restated in numpy."""
 from __future__ import annotations
 
-import ctypes as C
 from typing import Dict, Union
 
 import numpy as np
