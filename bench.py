@@ -4,6 +4,12 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Started plainly with --gpus N > 1 (no RANK in the environment) the script launches its own N ranks: before anything touches
+the GPU it checks that the node has N devices (exit code 3 with a message otherwise -- it never measures fewer ranks than
+asked for) and starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` with the
+same arguments as a CHILD process, passes its output through and exits with its code.  --dry-launch prints that command
+and starts nothing.  A WORLD_SIZE that disagrees with --gpus is an error (exit code 3), not a warning.
+
 One "step" = one pass of the hot path over one synthetic FakeSV batch (BASELINE.json configs[1]:
 full model, batch 32 per GPU, seq_len 128, one 224x224 frame), inputs resident in HBM:
   BERT-base text encoder fwd (bf16 MFMA) + ViT-B/32 visual encoder fwd (bf16 MFMA) -> pooled
@@ -136,6 +142,65 @@ def cpu_baseline(B: int, slice_b: int = 8, warm: int = 3, timed: int = 20, budge
                       f"(L={SEQ_LEN}, {FRAMES}x{IMAGE}^2 frame; per-sample work identical to B={B}){short}: {med * 1e3:.0f} ms/step "
                       f"(min {min(times) * 1e3:.0f}, max {max(times) * 1e3:.0f}); host has {os.cpu_count()} cpus"}
 
+def exchange_probe(tr, dev, n: int = 20):
+    """What RCCL saw: the process group's world size and the time of one gradient exchange of the step -- the two-bucket
+    all-reduce of the flat fp32 gradient arena, exactly as the step issues it -- alone on the GPU (median of `n`, HIP events
+    on the step's stream).  After the timed region; the gradient buffer is zeroed first (a sum of zeros costs the same and
+    cannot overflow).  None at one rank without a process group."""
+    if not dist.is_initialized():
+        return {"ranks_seen": 1, "allreduce_ms": None, "bytes": int(tr.arena.n_grad) * 4, "backend": None}
+    import statistics
+    g = tr.reducer.grad
+    g.zero_()
+    was = tr.reducer.force
+    tr.reducer.force = True                    # (world 1 under torchrun: run the collectives anyway)
+    times = []
+    for _ in range(n + 3):
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        tr.reducer.start()
+        tr.reducer.finish()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        times.append(e0.elapsed_time(e1))
+    tr.reducer.force = was
+    t = torch.tensor([statistics.median(times[3:])], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return {"ranks_seen": dist.get_world_size(), "allreduce_ms": round(float(t.item()), 4), "bytes": int(g.numel()) * 4,
+            "buckets": len(tr.reducer.buckets), "backend": dist.get_backend(),
+            "what": f"median of {n} two-bucket sum-all-reduces of the fp32 gradient arena, alone on the GPU, max over ranks"}
+
+
+def launch_command(n: int, argv: list, port: int) -> list:
+    """The torchrun command line `python bench.py --gpus n ...` turns itself into (one rank per GPU, RCCL over xGMI)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), str(Path(__file__).resolve())] + [a for a in argv if a != "--dry-launch"]
+
+
+def self_launch(args) -> None:
+    """--gpus N > 1 without a RANK in the environment: become the launcher.  Nothing in THIS process touches the GPU
+    (torch.cuda.device_count() does not initialise it on this image), so the ranks are ordinary children; their stdout
+    (rank 0's JSON line) and stderr pass through, and this process exits with torchrun's return code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = launch_command(args.gpus, sys.argv[1:], port)
+    if args.dry_launch:
+        print(json.dumps({"dry_launch": cmd}))
+        raise SystemExit(0)
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f"[bench] --gpus {args.gpus} but this node has {have} HIP device(s): refusing to measure fewer ranks than asked for",
+              file=sys.stderr)
+        raise SystemExit(3)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env, cwd=str(REPO)))
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -159,11 +224,19 @@ def main():
     ap.add_argument("--no-fuse-attn", action="store_true", help="text encoder: Q/K/V projection and attention as two launches per layer")
     ap.add_argument("--head-only", action="store_true",
                     help="secondary measurement: the reference's actual training mode (cached features, no encoders in the step)")
+    ap.add_argument("--dry-launch", action="store_true", help="--gpus N > 1 started plainly: print the torchrun command it would start, start nothing")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(args)                       # (never returns)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if rank == 0:
+            print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a number for a different rank count",
+                  file=sys.stderr)
+        raise SystemExit(3)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (MI355X); there is no CPU path to time as the product")
     torch.cuda.set_device(local)
@@ -173,8 +246,6 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         from ultrafnd_git_amd.dp import init_process_group
         init_process_group(dev)
-    if args.gpus != world and rank == 0:
-        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: using {world}", file=sys.stderr)
 
     from ultrafnd_git_amd.encoders import BertTextEncoder, ClipVisualEncoder
     from ultrafnd_git_amd.temporal import TemporalSyncNet
@@ -208,10 +279,12 @@ def main():
         dt = sorted(blocks)[len(blocks) // 2]
         P = tr.arena.n_grad
         gbps = 11 * 4 * P / (dt / args.steps) / 1e9
+        xch = exchange_probe(tr, dev)
         if rank == 0:
             print(json.dumps({"metric": "head-only train-step samples/sec (cached features: the reference's own training mode)",
                               "value": round(world * B * args.steps / dt, 1), "unit": "samples/s", "ms_per_step": round(dt / args.steps * 1e3, 4),
-                              "per_gpu_batch": B, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "per_gpu_batch": B, "n_gpus": world, "ranks_seen": xch["ranks_seen"], "exchange": xch,
+                              "steps": args.steps, "warmup": args.warmup,
                               "gradient_exchange": "bucketed all-reduce overlapped with backward" if tr.reducer.active else "none (one rank)",
                               "timing": {"what": f"median of {len(blocks)} blocks of {args.steps} steps",
                                          "ms_per_step_blocks": [round(x / args.steps * 1e3, 4) for x in blocks]},
@@ -343,6 +416,7 @@ def main():
                                "by_shape_MxNxK": {k: {"launches_per_encoder_pass": v[0] // 3, "avg_us": round(v[1] / v[0] * 1e3, 2),
                                                       "tflops": round(2.0 * eval(k.replace("x", "*")) / (v[1] / v[0] * 1e-3) / 1e12, 1)}
                                                   for k, v in tr.last_gemm_by_shape.items()}}}
+    xch = exchange_probe(tr, dev)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # (the CPU leg is timed at N = 1 only)
         cpu = cpu_baseline(B)
@@ -350,8 +424,8 @@ def main():
         value = world * B * args.steps / dt
         print(json.dumps({
             "metric": "train-step samples/sec (FakeSV batch, seq128+224^2)", "value": round(value, 2), "unit": "samples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "n_gpus": world, "ranks_seen": xch["ranks_seen"], "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("BASELINE configs[1]" if (SEQ_LEN, FRAMES, B) == (128, 1, 32) else "variant of BASELINE configs[1]") +
                                    f": full Ultrafnd step (BERT-base L={SEQ_LEN} fwd + {FRAMES} x ViT-B/32 224^2 fwd, frozen; "
                                    "fusion+classifier fwd/bwd, clip, AdamW)" +
@@ -364,7 +438,7 @@ def main():
             "timing": {"what": f"median of {len(blocks)} back-to-back blocks of {args.steps} steps, each between barrier + synchronize fences",
                        "ms_per_step_blocks": [round(x / args.steps * 1e3, 4) for x in blocks],
                        "ms_per_step_min": round(min(blocks) / args.steps * 1e3, 4), "ms_per_step_max": round(max(blocks) / args.steps * 1e3, 4)},
-            "lookahead_1": la1, "final_loss": final_loss, "roofline": roof, "cpu_baseline": cpu}))
+            "lookahead_1": la1, "final_loss": final_loss, "exchange": xch, "roofline": roof, "cpu_baseline": cpu}))
     if dist.is_initialized():
         dist.destroy_process_group()
 
