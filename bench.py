@@ -302,7 +302,8 @@ def main():
     if args.cu_split and args.cu_split != "0":
         split = tuple(int(x) for x in args.cu_split.split(","))
     cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir="/tmp/ufnd_bench", batch_size=B, device=str(dev),
-                      use_graph=not args.no_graph, encode_inline=True, seed=42, cu_split=split)
+                      use_graph=not args.no_graph, encode_inline=True, seed=42, cu_split=split,
+                      persistent_inputs=True)       # (the four input buffer sets below are rotated, never reallocated)
     tenc.fuse_qkv_attention = not args.no_fuse_attn
     for enc, spec in ((tenc, args.text_tiles), (venc, args.vis_tiles)):
         if spec:

@@ -28,7 +28,7 @@ extern "C" {
 #define UFND_ERR_INVALID 1 /* bad argument: shape, alignment, null pointer */
 #define UFND_ERR_LAUNCH 2  /* HIP launch error */
 
-#define UFND_ABI_VERSION 2
+#define UFND_ABI_VERSION 3
 
 const char* ufnd_last_error(void);
 int ufnd_abi_version(void);
@@ -286,6 +286,12 @@ int ufnd_gemm_bf16_stat_parts(int M, int N, int K);
 /* *guard = max(*guard, max over rows of |mean| * rstd) for the M rows of a statistics buffer (M, parts, 2) as
  * ufnd_gemm_bf16_ln writes and reads them (partial {sum, sumsq}; statistics over `width` elements). */
 int ufnd_ln_fold_guard(const float* stats, int M, int parts, int width, float eps, float* guard, void* stream);
+/* The same over `nbuf` statistics buffers of M rows each, `buf_stride` floats apart, in ONE launch: an encoder keeps one
+ * statistics buffer per folded LayerNorm of a pass (2 x layers of them, back to back) and looks at all of them with a single
+ * kernel at the end of the pass -- every row of every batch is guarded, at the price of re-reading the statistics once
+ * (75 MB per 16,384-row text pass). */
+int ufnd_ln_fold_guard_multi(const float* stats, int M, int parts, int nbuf, size_t buf_stride, int width, float eps, float* guard,
+                             void* stream);
 
 /* The tile table of this library: ids 0 .. ufnd_gemm_bf16_tile_count()-1; ufnd_gemm_bf16_tile_info returns 1 and the
  * block tile (rows x columns) of a tile that is built into the library (ln_aware: usable by ufnd_gemm_bf16_ln), 0 for

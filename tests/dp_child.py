@@ -1,10 +1,12 @@
 """Child of the data-parallel GPU tests (tests/test_gpu_dp.py), run under `python -m torch.distributed.run`.
 
-  --mode force1   world 1, backend nccl (= RCCL), UFND_FORCE_REDUCE=1: the bucketed, overlapped gradient exchange is
-                  live on one GPU.  Plain and pipelined steps through ForensicTrainer must leave the parameter arena
+  --mode force1   world 1, backend nccl (= RCCL), ForensicTrainer(force_exchange=True): the bucketed, overlapped gradient
+                  exchange is live on one GPU.  Plain and pipelined steps through ForensicTrainer must leave the parameter arena
                   bit-identical to the same steps without any exchange (a one-rank sum is the identity).
-  --mode world2   two ranks sharing cuda:0 over gloo (gradients staged through pinned host memory: a test seam, the
-                  product exchange is RCCL): sharded batches + summed gradients + 1/world == the single-process
+  --mode variants world 1, RCCL, forced exchange: the bf16-payload and the reduce-scatter + all-gather forms of the exchange run
+                  on the device (a one-rank sum: fp32 payloads leave the gradient unchanged, the bf16 payload rounds it once).
+  --mode world2   two ranks sharing cuda:0 over gloo (device tensors staged through host memory by tests/host_staged.py's
+                  Collectives subclass -- the product has no such path, its exchange is RCCL): sharded batches + summed gradients + 1/world == the single-process
                   full-batch step; then fit() / test() with sharded loaders, gathered metrics, the rank-0 checkpoint.
 Prints one JSON line on rank 0."""
 import argparse
@@ -14,6 +16,7 @@ import sys
 from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parent))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
@@ -23,10 +26,10 @@ import torch.distributed as dist
 DEV = torch.device("cuda", 0)
 
 
-def make_trainer(out_dir, B, use_graph=True, group=None, n=96, **kw):
+def make_trainer(out_dir, B, use_graph=True, group=None, n=96, force_exchange=False, **kw):
     from ultrafnd_git_amd.trainer import ForensicTrainer, TrainConfig, synthetic_cache
     cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir=out_dir, batch_size=B, device="cuda:0", use_graph=use_graph, **kw)
-    return ForensicTrainer(cfg, cache=synthetic_cache(n, seed=3), group=group)
+    return ForensicTrainer(cfg, cache=synthetic_cache(n, seed=3), group=group, force_exchange=force_exchange)
 
 
 def dict_batches(B, n, seed):
@@ -49,11 +52,8 @@ def force1(out_dir):
     for tag, active in (("exchange", True), ("plain", False)):
         for graph in (True, False):
             torch.manual_seed(5)
-            tr = make_trainer(out_dir, B, use_graph=graph)
-            assert tr.reducer.force and tr.reducer.active and len(tr.reducer.buckets) == 2
-            if not active:
-                tr.reducer.force = False
-                assert not tr.reducer.active
+            tr = make_trainer(out_dir, B, use_graph=graph, force_exchange=active)
+            assert tr.reducer.force == active and tr.reducer.active == active and len(tr.reducer.buckets) == 2
             tr.fusion.train(); tr.clf.train()
             for b in dict_batches(B, 3, 11):
                 out = tr.train_step(b)
@@ -75,9 +75,7 @@ def force1(out_dir):
         tenc.load_state_dict(wt); venc.load_state_dict(wv)
         tenc, venc = tenc.to(DEV), venc.to(DEV)
         cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir=out_dir, batch_size=8, device="cuda:0", use_graph=True, encode_inline=True)
-        tr = ForensicTrainer(cfg, cache=synthetic_cache(32, seed=1), text_encoder=tenc, visual_encoder=venc)
-        if not active:
-            tr.reducer.force = False
+        tr = ForensicTrainer(cfg, cache=synthetic_cache(32, seed=1), text_encoder=tenc, visual_encoder=venc, force_exchange=active)
         tr.fusion.train(); tr.clf.train()
         raws = []
         for k in range(3):
@@ -100,9 +98,7 @@ def force1(out_dir):
         tenc.load_state_dict(wt); venc.load_state_dict(wv)
         tenc, venc = tenc.to(DEV), venc.to(DEV)
         cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir=out_dir, batch_size=8, device="cuda:0", use_graph=True, encode_inline=True)
-        tr = ForensicTrainer(cfg, cache=synthetic_cache(32, seed=1), text_encoder=tenc, visual_encoder=venc)
-        if not active:
-            tr.reducer.force = False
+        tr = ForensicTrainer(cfg, cache=synthetic_cache(32, seed=1), text_encoder=tenc, visual_encoder=venc, force_exchange=active)
         tr.fusion.train(); tr.clf.train()
         groups = []
         for k in range(2):
@@ -131,18 +127,20 @@ def world2(out_dir):
         torch.manual_seed(5)
         tr0 = make_trainer(os.path.join(out_dir, "ref"), B, use_graph=False)
         tr0.fusion.dropout = tr0.clf.dropout = tr0.clf.node_dropout = 0.0
-        tr0._step_bufs.clear()
+        tr0.head.step_bufs.clear()
         tr0.fusion.train(); tr0.clf.train()
         for b in batches:
             o = tr0.train_step(b)
         ref = (tr0.arena.data.clone(), float(tr0.optim.state.read().grad_norm))
         del tr0
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    from host_staged import HostStagedCollectives
+    comm = HostStagedCollectives()
     torch.manual_seed(5)
-    tr = make_trainer(out_dir, B // world, use_graph=True)
+    tr = make_trainer(out_dir, B // world, use_graph=True, group=comm)
     assert tr.world == world and tr.reducer.active and abs(tr.reducer.grad_scale - 0.5) < 1e-12
     tr.fusion.dropout = tr.clf.dropout = tr.clf.node_dropout = 0.0
-    tr._step_bufs.clear()
+    tr.head.step_bufs.clear()
     tr.fusion.train(); tr.clf.train()
     for b in batches:
         shard = {k: v[rank::world].contiguous() for k, v in b.items()}
@@ -154,7 +152,7 @@ def world2(out_dir):
         err = (tr.arena.data - ref[0]).abs().max().item()
         scale = ref[0].abs().max().item()
         res.update({"param_max_abs_err": err, "param_scale": scale, "grad_norm": gn, "grad_norm_ref": ref[1],
-                    "via_host": bool(tr.reducer._via_host)})
+                    "via_host": comm.staged_calls > 0})
     # every rank holds the same parameters after the exchange
     mine = tr.arena.data.cpu()
     other = [torch.empty_like(mine) for _ in range(world)]
@@ -169,7 +167,7 @@ def world2(out_dir):
     cache["text"] = t / np.linalg.norm(t, axis=1, keepdims=True)
     cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir=os.path.join(out_dir, "fit"), batch_size=8, epochs=3, device="cuda:0",
                       lr=1e-3, early_stop_patience=8)
-    tr2 = ForensicTrainer(cfg, cache=cache)
+    tr2 = ForensicTrainer(cfg, cache=cache, group=comm)
     best = tr2.fit()
     out = tr2.test()
     vals = torch.tensor([best, out["test_auc"], out["test_loss"]], dtype=torch.float64)
@@ -188,10 +186,38 @@ def world2(out_dir):
     dist.destroy_process_group()
 
 
+def variants(out_dir):
+    """The exchange variants on the device (RCCL, one rank): every form must run inside the step (graphs, two buckets, overlap),
+    fp32 payloads must not change a bit of a one-rank sum, the bf16 payload must equal one bf16 rounding of the gradient."""
+    from ultrafnd_git_amd.dp import init_process_group
+    init_process_group(DEV)
+    res, B, arenas = {}, 16, {}
+    for tag, kw in (("plain", None), ("ar_fp32", dict(grad_payload="fp32", grad_exchange="all_reduce")),
+                    ("rsag_fp32", dict(grad_payload="fp32", grad_exchange="rs_ag")), ("ar_bf16", dict(grad_payload="bf16", grad_exchange="all_reduce")),
+                    ("rsag_bf16", dict(grad_payload="bf16", grad_exchange="rs_ag"))):
+        torch.manual_seed(5)
+        tr = make_trainer(out_dir, B, use_graph=True, force_exchange=kw is not None, **(kw or {}))
+        tr.fusion.train(); tr.clf.train()
+        for b in dict_batches(B, 2, 11):
+            out = tr.train_step(b)
+        torch.cuda.synchronize()
+        arenas[tag] = (tr.arena.data.clone(), tr.arena.grad.clone())
+        res[tag + "_wire_MB"] = round(tr.reducer.wire_bytes() / 1e6, 2)
+    ref = arenas["plain"]
+    res["fp32_forms_bit_identical"] = bool(torch.equal(arenas["ar_fp32"][0], ref[0]) and torch.equal(arenas["rsag_fp32"][0], ref[0]))
+    res["bf16_forms_agree"] = bool(torch.equal(arenas["ar_bf16"][0], arenas["rsag_bf16"][0]))
+    g = arenas["ar_bf16"][1]
+    res["bf16_grad_is_bf16_valued"] = bool(torch.equal(g, g.to(torch.bfloat16).float()))
+    res["bf16_param_max_rel"] = float(((arenas["ar_bf16"][0] - ref[0]).abs().max() / ref[0].abs().max()).item())
+    res["backend"] = dist.get_backend()
+    print(json.dumps(res))
+    dist.destroy_process_group()
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", required=True)
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     torch.cuda.set_device(0)
-    {"force1": force1, "world2": world2}[a.mode](a.out)
+    {"force1": force1, "world2": world2, "variants": variants}[a.mode](a.out)

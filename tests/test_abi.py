@@ -23,7 +23,8 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 10
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.ufnd_abi_version() == 2
+    from ultrafnd_git_amd import _lib as L
+    assert lib.ufnd_abi_version() == L.ABI_VERSION == 3
 
 
 def test_struct_mirrors_match_header_sizes():
@@ -50,6 +51,19 @@ def test_product_never_imports_the_oracle():
     for f in (REPO / "ultrafnd_git_amd").rglob("*.py"):
         src = f.read_text()
         assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_product_reads_no_environment_override():
+    """No test seam or experiment switch hides behind an environment variable: the package's Python reads none (build.py's
+    HIPCC -- which compiler binary to run -- is the one exception), and the library's strings name no UFND_* variable."""
+    import torch  # noqa: F401
+    from ultrafnd_git_amd.build import build
+    for f in (REPO / "ultrafnd_git_amd").rglob("*.py"):
+        src = f.read_text()
+        for m in re.finditer(r"environ(?:\.get)?\s*[\[(]\s*[\"']([A-Za-z0-9_]+)", src):
+            assert f.name == "build.py" and m.group(1) == "HIPCC", (f.name, m.group(1))
+        assert "getenv" not in src, f
+    assert not re.search(rb"UFND_[A-Z_]{3,}", Path(build()).read_bytes())
 
 
 def test_diagnostics_are_not_reachable_through_the_product_library():

@@ -57,8 +57,26 @@ def _worker(rank, world, port, q, tmp):
                 o, shape = arena.offsets[k]
                 got = mean[o:o + ref[k].numel()].view(shape)
                 worst = max(worst, (got - ref[k]).abs().max().item() / max(1e-6, ref[k].abs().max().item()))
+        # exchange variants: reduce-scatter + all-gather sums the same addends per element, and the bf16
+        # payload is the sum of the two ranks' bf16-rounded gradients, itself rounded to bf16 (by the collective)
+        variants = {}
+        odd = arena.grad.numel() - 3                   # (a bucket whose length the world size does not divide)
+        for tag, kw in (("rsag", dict(algorithm="rs_ag")), ("bf16", dict(payload="bf16")), ("bf16_rsag", dict(payload="bf16", algorithm="rs_ag"))):
+            arena.grad.copy_(local)
+            r3 = GradReducer(arena.grad, bounds=[cut, odd], **kw)
+            r3.start(0); r3.start(1); r3.start(2); r3.finish()
+            got = arena.grad * r3.grad_scale
+            both = [torch.empty_like(local) for _ in range(world)]
+            dist.all_gather(both, local)
+            if "bf16" in tag:
+                want = (both[0].bfloat16() + both[1].bfloat16()).float() * r3.grad_scale
+                variants[tag] = (bool(torch.equal(got, want)), r3.wire_bytes() * 2 == arena.grad.numel() * 4,
+                                 float(((got - mean).abs().max() / mean.abs().max()).item()))
+            else:
+                variants[tag] = (bool(torch.equal(got, mean)), r3.wire_bytes() == arena.grad.numel() * 4, 0.0)
         rows = gather_rows(torch.arange(4.0).view(4, 1) + 10 * rank)
         extra = _epoch_level_checks(rank, world, tmp)
+        extra["variants"] = variants
         if rank == 0:
             q.put(("ok", worst, rows.flatten().tolist(), extra))
     except Exception as e:  # pragma: no cover
@@ -131,6 +149,10 @@ def test_two_rank_gradient_allreduce_equals_full_batch(tmp_path):
     assert extra["bcast"] == [1.0] * 5
     assert sorted(extra["eval_rows"]) == [float(i) for i in range(extra["eval_n"])]              # every row once, none twice
     assert extra["train_rows_per_rank"] == [14.0, 14.0]
+    v = extra["variants"]
+    assert v["rsag"][0] and v["rsag"][1]                       # reduce-scatter + all-gather: the all-reduce's bits, fp32 on the wire
+    assert v["bf16"][0] and v["bf16"][1] and v["bf16_rsag"][0]  # bf16 payload: exactly the bf16 sum of the bf16-rounded shards, half the bytes
+    assert 0.0 < v["bf16"][2] < 2 ** -7                         # ... within bf16 rounding of the fp32 mean
 
 
 def test_shard_indices_partition_and_padding():

@@ -27,17 +27,17 @@ def _run(launch_job, nproc, mode, out_dir, env):
 
 
 def test_forced_rccl_exchange_on_one_rank_changes_no_bit(launch_job, tmp_path):
-    """torchrun world 1, RCCL, UFND_FORCE_REDUCE=1: init_process_group (high-priority group stream), the two-bucket
+    """torchrun world 1, RCCL, ForensicTrainer(force_exchange=True): init_process_group (high-priority group stream), the two-bucket
     asynchronous all-reduce started inside backward (two captured head graphs with the collectives between them),
     grad_scale in the norm / AdamW, graph capture with the process group alive -- three plain steps (graph and eager)
     and three pipelined steps leave the arena bit-identical to the same steps without any exchange."""
-    res = _run(launch_job, 1, "force1", tmp_path, {"UFND_FORCE_REDUCE": "1"})
+    res = _run(launch_job, 1, "force1", tmp_path, {})
     assert res["backend"] == "nccl" and res["steps"] == 3
     assert res["plain_steps_bit_identical"] and res["pipelined_bit_identical"] and res["lookahead_bit_identical"], res
 
 
 def test_two_ranks_on_one_gpu_equal_the_full_batch_step(launch_job, tmp_path):
-    """Two ranks sharing the GPU (gloo; gradients through pinned host memory): sharded batch + summed bucketed
+    """Two ranks sharing the GPU (gloo; device tensors through host memory by tests/host_staged.py -- not a product path): sharded batch + summed bucketed
     gradients + 1/world folded into grad_scale == the single-process full-batch trainer, three steps; then fit() /
     test() over sharded loaders: gathered metrics agree on both ranks, evaluation shards partition the split
     (no wrapped duplicates), rank 0 checkpoints and every rank tests with rank 0's parameters."""
@@ -47,3 +47,15 @@ def test_two_ranks_on_one_gpu_equal_the_full_batch_step(launch_job, tmp_path):
     assert abs(res["grad_norm"] - res["grad_norm_ref"]) <= 1e-4 * max(1.0, res["grad_norm_ref"]), res
     assert res["val_rows_total"] == res["val_rows_split"], res
     assert 0.5 < res["best_val_auc"] <= 1.0
+
+
+def test_exchange_variants_run_on_the_device(launch_job, tmp_path):
+    """torchrun world 1, RCCL, forced exchange: bf16 gradient payload (25.5 MB instead of 51) and reduce-scatter + all-gather,
+    inside the captured two-bucket step.  A one-rank sum: the fp32 forms change no bit; the bf16 form is one rounding of the
+    gradient (the arena's parameters stay within bf16 rounding of the plain run after two steps).  World-2 numerics of the
+    same variants: tests/test_dp_gloo.py."""
+    res = _run(launch_job, 1, "variants", tmp_path, {})
+    assert res["backend"] == "nccl"
+    assert res["fp32_forms_bit_identical"] and res["bf16_forms_agree"] and res["bf16_grad_is_bf16_valued"], res
+    assert res["ar_bf16_wire_MB"] * 2 == pytest.approx(res["ar_fp32_wire_MB"], rel=1e-3)
+    assert 0.0 < res["bf16_param_max_rel"] < 1e-3, res

@@ -84,7 +84,7 @@ def test_integrated_step_matches_the_oracle(tmp_path):
     tr.fusion.load_state_dict(fus_sd); tr.clf.load_state_dict(clf_sd); tr.gnn_model.load_state_dict(w_gnn)
     tr.fusion.dropout = tr.clf.dropout = tr.clf.node_dropout = 0.0
     tr.gnn_model.dropout = 0.0
-    tr._step_bufs.clear()
+    tr.head.step_bufs.clear()
     assert tr.arena.n_grad >= 12_745_949 + 416 * 256 + 256 + 256 * 128 + 128
     tr.fusion.train(); tr.clf.train()
     batch = next(iter(tr.val_loader))                      # deterministic order: rows 0..7 of the validation split

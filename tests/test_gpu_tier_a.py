@@ -274,7 +274,7 @@ def test_cosine_schedule_and_criterion_options_in_the_trainer():
     cache = synthetic_cache(80, seed=2)
     tr = ForensicTrainer(cfg, cache=cache)
     y = cache["labels"]
-    assert abs(tr._ce_w[0] - 0.5 * len(y) / max(1, (y == 0).sum())) < 1e-9
+    assert abs(tr.head.ce_w[0] - 0.5 * len(y) / max(1, (y == 0).sum())) < 1e-9
     loss, _ = tr._epoch_loop(tr.train_loader, "train")
     assert math.isfinite(loss)
     lrs = []

@@ -77,7 +77,7 @@ def main():
     tr = ForensicTrainer(cfg, cache=synthetic_cache(64, seed=1))
     tr.fusion.load_state_dict(fus0); tr.clf.load_state_dict(clf0)
     tr.fusion.dropout = tr.clf.dropout = tr.clf.node_dropout = 0.0
-    tr._step_bufs.clear()
+    tr.head.step_bufs.clear()
     hip_logs, hip_norms = [], []
     hb = {k: v.to(DEV) for k, v in held.items()}
     for i, b in enumerate(stream):

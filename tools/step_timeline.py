@@ -26,7 +26,7 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     import os
-    if "RANK" in os.environ:          # under torchrun: the data-parallel path (UFND_FORCE_REDUCE=1 runs the collective at world 1)
+    if "RANK" in os.environ:          # under torchrun: the data-parallel path (force_exchange=True runs the collective at world 1)
         import torch.distributed as dist
         torch.cuda.set_device(dev)
         dist.init_process_group("nccl", device_id=dev)
@@ -36,7 +36,8 @@ def main():
     cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir="/tmp/ufnd_tl", batch_size=B, device=str(dev), use_graph=True,
                       encode_inline=True, seed=42)
     tsync = TemporalSyncNet(in_dim=768, out_dim=256).to(dev)
-    tr = ForensicTrainer(cfg, cache=synthetic_cache(64, seed=1), text_encoder=tenc, visual_encoder=venc, temporal_net=tsync)
+    tr = ForensicTrainer(cfg, cache=synthetic_cache(64, seed=1), text_encoder=tenc, visual_encoder=venc, temporal_net=tsync,
+                         force_exchange="RANK" in os.environ)
     tr.fusion.train(); tr.clf.train()
     batches = bench.make_batches(B, 4, 45, dev)
 
@@ -51,13 +52,13 @@ def main():
 
     run(5)
     torch.cuda.synchronize()
-    tr._timeline = []
+    tr.pipe.timeline = []
     t0 = time.perf_counter()
     host = run(args.steps)
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / args.steps
-    tl = tr._timeline
-    tr._timeline = None
+    tl = tr.pipe.timeline
+    tr.pipe.timeline = None
     # split into steps at every "step0"
     steps, cur = [], None
     for tag, ev in tl:

@@ -12,8 +12,7 @@ from typing import Optional
 import torch
 
 _PKG = Path(__file__).resolve().parent
-import os as _os
-LIB_PATH = Path(_os.environ.get("UFND_LIB", _PKG / "libultrafnd_hip.so"))      # (UFND_LIB: A/B of two builds in one run)
+LIB_PATH = _PKG / "libultrafnd_hip.so"      # (tools that A/B two builds set this before the first lib() call)
 
 
 class UltrafndHipError(RuntimeError):
@@ -78,7 +77,7 @@ class GemmLn(C.Structure):
 
 STEP_STATE_BYTES = C.sizeof(StepState)
 BWD_ALL, BWD_FUSE_MLP, BWD_REST = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib: Optional[C.CDLL] = None
 
@@ -136,6 +135,7 @@ def _declare_encoders(lib: C.CDLL) -> None:
         "ufnd_gemm_bf16_ln": [P] * 6 + [I] * 9 + [C.POINTER(GemmLn), P],
         "ufnd_gemm_bf16_stat_parts": [I, I, I],
         "ufnd_ln_fold_guard": [P, I, I, I, F, P, P],
+        "ufnd_ln_fold_guard_multi": [P, I, I, I, S, I, F, P, P],
         "ufnd_gemm_bf16_tile_count": [],
         "ufnd_gemm_bf16_tile_info": [I, C.POINTER(I), C.POINTER(I), C.POINTER(I)],
         "ufnd_stream_create_cu_mask": [C.POINTER(C.c_uint32), I, C.POINTER(P)],

@@ -1,6 +1,6 @@
 """Build the HIP libraries in-tree with hipcc for gfx950 (MI355X).
 
-    python -m ultrafnd_git_amd.build [--verbose] [--force] [--diag]
+    python -m ultrafnd_git_amd.build [--verbose] [--force] [--diag] [--defs=A,B=1]     (--defs: extra -D switches, experiments)
 
   libultrafnd_hip.so        the product: every source of csrc/*.hip (include/ultrafnd_hip.h)
   libultrafnd_hip_diag.so   diagnostics only (csrc/diag/*.hip, built with -DUFND_DIAG): timing ablations, in-kernel
@@ -34,8 +34,11 @@ def diag_sources():
     return sorted((CSRC / "diag").glob("*.hip")) + [CSRC / "api.hip"]
 
 
+EXTRA_DEFS: list = []      # experiments: extra -D switches (python -m ultrafnd_git_amd.build --defs=A,B=1); part of the build digest
+
+
 def _defs() -> list:
-    return ["-D" + d for d in os.environ.get("UFND_BUILD_DEFS", "").split(",") if d]      # experiments: extra -D switches
+    return ["-D" + d for d in EXTRA_DEFS if d]
 
 
 def _digest(extra: str) -> str:
@@ -97,6 +100,9 @@ def build_diag(force: bool = False, verbose: bool = False) -> Path:
 
 
 if __name__ == "__main__":
+    for a in sys.argv[1:]:
+        if a.startswith("--defs="):
+            EXTRA_DEFS[:] = a[len("--defs="):].split(",")
     p = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv)
     print(p)
     if "--diag" in sys.argv:

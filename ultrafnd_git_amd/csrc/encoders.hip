@@ -389,13 +389,26 @@ extern "C" int ufnd_field_mean_l2(const float* parts, const int32_t* valid, floa
 // Fold guard: the largest |mean| / std among the rows of a LayerNorm-statistics buffer (see ufnd_gemm_bf16_ln).
 // ------------------------------------------------------------------------------------------------
 namespace {
-__global__ __launch_bounds__(256) void ln_fold_guard_kernel(const float* stats, int M, int parts, float inv_h, float eps, float* guard) {
+// Four lanes per row: lane j of a quad adds 16-B chunks j, j + 4, ... of the row's `parts` {sum, sumsq} pairs (parts is even),
+// the quad combines by DPP.  Rows are `nbuf` buffers of M rows each, `buf_stride` floats apart (one launch looks at every
+// statistics buffer of an encoder pass).
+__global__ __launch_bounds__(256) void ln_fold_guard_kernel(const float* stats, int M, int parts, int nbuf, size_t buf_stride, float inv_h,
+                                                            float eps, float* guard) {
   __shared__ float sh[4];
   float worst = 0.0f;
-  for (int row = blockIdx.x * 256 + threadIdx.x; row < M; row += gridDim.x * 256) {
-    const float* p = stats + (size_t)row * parts * 2;
+  const int nq = parts >> 1, sub = threadIdx.x & 3;
+  const long long total = (long long)M * nbuf;
+  for (long long r = (long long)blockIdx.x * 64 + (threadIdx.x >> 2); r < total; r += (long long)gridDim.x * 64) {
+    const int bi = (int)(r / M), row = (int)(r - (long long)bi * M);
+    const f32x4* p = reinterpret_cast<const f32x4*>(stats + bi * buf_stride + (size_t)row * parts * 2);
     float sm = 0.0f, sq = 0.0f;
-    for (int i = 0; i < parts; ++i) { sm += p[2 * i]; sq += p[2 * i + 1]; }
+    for (int c = sub; c < nq; c += 4) {
+      const f32x4 v = p[c];
+      sm += v[0] + v[2];
+      sq += v[1] + v[3];
+    }
+    sm += quad_xor1(sm); sq += quad_xor1(sq);
+    sm += quad_xor2(sm); sq += quad_xor2(sq);
     const float mean = sm * inv_h;
     const float var = fmaxf(sq * inv_h - mean * mean, 0.0f);
     worst = fmaxf(worst, fabsf(mean) * rsqrtf(var + eps));
@@ -408,10 +421,20 @@ __global__ __launch_bounds__(256) void ln_fold_guard_kernel(const float* stats, 
 }
 }  // namespace
 
-extern "C" int ufnd_ln_fold_guard(const float* stats, int M, int parts, int width, float eps, float* guard, void* stream_) {
-  UFND_REQUIRE(stats && guard && M >= 1 && parts >= 1 && width >= 1, "ln_fold_guard: bad argument");
-  const int blocks = ufnd_cdiv(M, 256) < 64 ? ufnd_cdiv(M, 256) : 64;
-  hipLaunchKernelGGL(ln_fold_guard_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, stats, M, parts, 1.0f / (float)width, eps, guard);
+extern "C" int ufnd_ln_fold_guard_multi(const float* stats, int M, int parts, int nbuf, size_t buf_stride, int width, float eps, float* guard,
+                                        void* stream_) {
+  UFND_REQUIRE(stats && guard && M >= 1 && parts >= 2 && parts % 2 == 0 && nbuf >= 1 && width >= 1 && ufnd_aligned(stats, 16) &&
+               (nbuf == 1 || (buf_stride % 4 == 0 && buf_stride >= (size_t)M * parts * 2)),
+               "ln_fold_guard: M=%d parts=%d (even) nbuf=%d stride=%zu", M, parts, nbuf, buf_stride);
+  const long long rows = (long long)M * nbuf;
+  const long long want = (rows + 63) / 64;
+  const int blocks = (int)(want < 2048 ? want : 2048);
+  hipLaunchKernelGGL(ln_fold_guard_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, stats, M, parts, nbuf, buf_stride,
+                     1.0f / (float)width, eps, guard);
   UFND_CHECK_LAUNCH();
   return UFND_OK;
+}
+
+extern "C" int ufnd_ln_fold_guard(const float* stats, int M, int parts, int width, float eps, float* guard, void* stream_) {
+  return ufnd_ln_fold_guard_multi(stats, M, parts, 1, 0, width, eps, guard, stream_);
 }

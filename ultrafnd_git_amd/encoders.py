@@ -55,11 +55,11 @@ class _EncoderBase(nn.Module):
     def __init__(self):
         super().__init__()
         self.tiles = {}
-        self._guard: Optional[torch.Tensor] = None
-        self.guarded = False          # True while a pass also evaluates the fold guard (one tiny kernel per folded LayerNorm)
+        self._guard: Optional[torch.Tensor] = None      # device float: largest |mean| / std any folded LayerNorm has seen
         self._w: "OrderedDict[str, torch.Tensor]" = OrderedDict()
         self._packed: Optional[dict] = None
         self._bufs: Dict[Tuple, dict] = {}
+        self.weights_version = 0      # bumped whenever the packed operands are invalidated (captured graphs name them)
 
     # ---- state_dict with the third-party names
     def state_dict(self, *args, **kwargs):
@@ -76,6 +76,7 @@ class _EncoderBase(nn.Module):
                     raise RuntimeError(f"shape mismatch for {k}: {tuple(sd[k].shape)} vs {tuple(self._w[k].shape)}")
                 self._w[k].copy_(sd[k].to(self._w[k].device, torch.float32))
         self._packed = None
+        self.weights_version += 1
         return missing, unexpected
 
     def _apply(self, fn, recurse=True):
@@ -84,6 +85,7 @@ class _EncoderBase(nn.Module):
             self._w[k] = fn(self._w[k]).float()
         self._packed = None
         self._bufs.clear()
+        self.weights_version += 1
         return self
 
     @property
@@ -130,25 +132,32 @@ class _EncoderBase(nn.Module):
                                           out_bf16.stride(0) if out_bf16 is not None else 0,
                                           out_f32.stride(0) if out_f32 is not None else 0, act, ctypes.byref(ln),
                                           L.stream_ptr(A.device)), "ufnd_gemm_bf16_ln")
-        if self.guarded and a_stats is not None:
-            # a guarded pass (strict forwards, the trainer's once-per-epoch check) looks at every statistics buffer a
-            # folded LayerNorm consumes, right where it is consumed
-            if self._guard is None or self._guard.device != A.device:
-                self._guard = torch.zeros(1, dtype=torch.float32, device=A.device)
-            L.check(L.lib().ufnd_ln_fold_guard(a_stats.data_ptr(), M, a_stats.shape[1], self.hidden, eps, self._guard.data_ptr(),
-                                               L.stream_ptr(A.device)), "ufnd_ln_fold_guard")
+
+    def _guard_buf(self, dev) -> torch.Tensor:
+        if self._guard is None or self._guard.device != dev:
+            self._guard = torch.zeros(1, dtype=torch.float32, device=dev)
+        return self._guard
+
+    def _guard_pass(self, st: torch.Tensor, M: int) -> None:
+        """The fold guard of a pass: ONE launch over every statistics buffer the pass wrote (st: (nbuf, rows, parts, 2), the
+        first M rows of each are live).  Part of every folded forward -- captured graphs included -- so every row of every
+        batch is looked at; the host reads the flag when it chooses to (check_fold)."""
+        nbuf = st.shape[0] if st.dim() == 4 else 1
+        L.check(L.lib().ufnd_ln_fold_guard_multi(st.data_ptr(), M, st.shape[-2], nbuf, st.stride(0) if st.dim() == 4 else 0, self.hidden,
+                                                 self.eps, self._guard_buf(st.device).data_ptr(), L.stream_ptr(st.device)),
+                "ufnd_ln_fold_guard_multi")
 
     def fold_ratio(self) -> float:
-        """Largest |mean| / std over the rows whose LayerNorm was folded in the GUARDED passes since the last reset
-        (synchronises)."""
+        """Largest |mean| / std over the rows that went through a folded LayerNorm since the last reset (synchronises)."""
         return 0.0 if self._guard is None else float(self._guard.cpu())
 
-    def check_fold(self, reset: bool = True) -> bool:
-        """The fold guard: True (and folding switched off for every later call, buffers rebuilt) when a guarded pass saw
-        a folded row whose |mean| / std exceeds FOLD_GUARD_MAX.  Guarded passes: every `strict=True` forward (the offline
-        feature builder: checked after each batch, which is then repeated unfolded) and one pass per epoch of the
-        trainer (`guarded_pass`; the ratio is a property of the weights much more than of one input)."""
-        r = self.fold_ratio()
+    def check_fold(self, reset: bool = True, ratio: Optional[float] = None) -> bool:
+        """The fold guard: True (and folding switched off for every later call, buffers rebuilt) when a folded row's
+        |mean| / std exceeded FOLD_GUARD_MAX.  Every folded forward evaluates the guard on the device (one launch at the
+        end of the pass, inside captured graphs too); this reads it: `strict=True` forwards after each batch (which is then
+        repeated unfolded), the trainer after every encoder pass through an asynchronous copy (`ratio=` hands that value in,
+        so that nothing synchronises)."""
+        r = self.fold_ratio() if ratio is None else float(ratio)
         if reset and self._guard is not None:
             self._guard.zero_()
         if self.fold_ln and r > self.FOLD_GUARD_MAX:
@@ -159,17 +168,6 @@ class _EncoderBase(nn.Module):
             self._bufs.clear()
             return True
         return False
-
-    def guarded_pass(self, *inputs) -> bool:
-        """One eager forward over `inputs` with the guard evaluated, then check_fold(): the trainer's per-epoch check."""
-        if not self.fold_ln:
-            return False
-        self.guarded = True
-        try:
-            self.forward(*inputs)
-        finally:
-            self.guarded = False
-        return self.check_fold()
 
     @staticmethod
     def _fold(W, b, gamma, beta):
@@ -192,11 +190,6 @@ class _EncoderBase(nn.Module):
         L.check(L.lib().ufnd_qkv_attention_bf16(A.data_ptr(), W.data_ptr(), L.ptr(bias), L.ptr(mask_i32), ctx.data_ptr(), B, Lq, heads,
                                                 A.stride(0), W.stride(0), ctypes.byref(ln) if ln is not None else None,
                                                 L.stream_ptr(A.device)), "ufnd_qkv_attention_bf16")
-        if self.guarded and a_stats is not None:
-            if self._guard is None or self._guard.device != A.device:
-                self._guard = torch.zeros(1, dtype=torch.float32, device=A.device)
-            L.check(L.lib().ufnd_ln_fold_guard(a_stats.data_ptr(), A.shape[0], a_stats.shape[1], self.hidden, eps, self._guard.data_ptr(),
-                                               L.stream_ptr(A.device)), "ufnd_ln_fold_guard")
 
     def _attn(self, qkv, mask_i32, ctx, B, Lq, heads):
         L.check(L.lib().ufnd_attention_bf16(qkv.data_ptr(), L.ptr(mask_i32), ctx.data_ptr(), B, Lq, heads,
@@ -278,9 +271,12 @@ class BertTextEncoder(_EncoderBase):
                                "h": torch.empty(M, self.inter, **bf), "feat": torch.empty(B, H, **f32)}
             p1 = L.lib().ufnd_gemm_bf16_stat_parts(M, H, H)
             p2 = L.lib().ufnd_gemm_bf16_stat_parts(M, H, self.inter)
-            if self.fold_ln and p1 > 0 and p2 > 0 and p1 % 2 == 0 and p2 % 2 == 0:
+            if self.fold_ln and p1 > 0 and p1 == p2 and p1 % 2 == 0:
+                # one statistics buffer per folded LayerNorm of the pass (st[2i]: layer i's attention half, st[2i+1]: its
+                # feed-forward half), so that ONE guard launch at the end of the pass sees every row (_guard_pass)
                 self._bufs[key].update({"y2": torch.empty(M, H, **f32), "y1b": torch.empty(M, H, **bf), "y2b": torch.empty(M, H, **bf),
-                                        "st1": torch.zeros(M, p1, 2, **f32), "st2": torch.zeros(M, p2, 2, **f32)})
+                                        "st": torch.zeros(2 * self.layers, M, p1, 2, **f32)})
+                self._guard_buf(dev)
         return self._bufs[key]
 
     @torch.no_grad()
@@ -311,8 +307,8 @@ class BertTextEncoder(_EncoderBase):
         """The encoder layers over the first M rows of the work buffers; attn(qkv, ctx) runs the attention (padded
         batch or packed sequences).  Leaves last_hidden_state in b["xf"] (and its bf16 rounding in b["xb"])."""
         H = self.hidden
-        v = {k: (x[:M] if torch.is_tensor(x) and x.dim() >= 2 and x.shape[0] >= M and k != "feat" else x) for k, x in b.items()}
-        if "st1" in b:
+        v = {k: (x[:M] if torch.is_tensor(x) and x.dim() >= 2 and x.shape[0] >= M and k not in ("feat", "st") else x) for k, x in b.items()}
+        if "st" in b:
             return self._layers_folded(p, v, M, attn, fused)
         for ly in p["layers"]:
             if fused is not None:
@@ -331,30 +327,34 @@ class BertTextEncoder(_EncoderBase):
         PRE-LayerNorm sums of the attention and the feed-forward halves (fp32 + bf16 + row statistics)."""
         H, eps = self.hidden, self.eps
         y1, y2 = b["y"], b["y2"]
+        st = b["st"]
         prev = None
-        for ly in p["layers"]:
+        for i, ly in enumerate(p["layers"]):
+            st1, st2 = st[2 * i][:M], st[2 * i + 1][:M]
+            stp = st[2 * i - 1][:M] if i > 0 else None           # the previous layer's feed-forward half
             if fused is not None:
                 if prev is None:
                     self._qkv_attn(b["xb"], ly["wqkv"], ly["bqkv"], fused[2], b["ctx"], fused[0], fused[1], self.heads)
                 else:
                     self._qkv_attn(b["y2b"], ly["wqkvf"], ly["bqkvf"], fused[2], b["ctx"], fused[0], fused[1], self.heads,
-                                   a_stats=b["st2"], colsum=ly["csqkv"], eps=eps)
+                                   a_stats=stp, colsum=ly["csqkv"], eps=eps)
             elif prev is None:      # layer 0 consumes the embeddings' own (materialised) LayerNorm
                 self._gemm(b["xb"], ly["wqkv"], ly["bqkv"], out_bf16=b["qkv"], which="qkv")
             else:
-                self._gemm_ln(b["y2b"], ly["wqkvf"], ly["bqkvf"], out_bf16=b["qkv"], a_stats=b["st2"], colsum=ly["csqkv"], eps=eps, which="qkv")
+                self._gemm_ln(b["y2b"], ly["wqkvf"], ly["bqkvf"], out_bf16=b["qkv"], a_stats=stp, colsum=ly["csqkv"], eps=eps, which="qkv")
             if fused is None:
                 attn(b["qkv"], b["ctx"])
             if prev is None:
-                self._gemm_ln(b["ctx"], ly["wo"], ly["bo"], out_f32=y1, out_bf16=b["y1b"], residual=b["xf"], out_stats=b["st1"], eps=eps, which="out")
+                self._gemm_ln(b["ctx"], ly["wo"], ly["bo"], out_f32=y1, out_bf16=b["y1b"], residual=b["xf"], out_stats=st1, eps=eps, which="out")
             else:
-                self._gemm_ln(b["ctx"], ly["wo"], ly["bo"], out_f32=y1, out_bf16=b["y1b"], residual=y2, r_stats=b["st2"],
-                              r_gamma=prev["g2"], r_beta=prev["b2n"], out_stats=b["st1"], eps=eps, which="out")
-            self._gemm_ln(b["y1b"], ly["w1f"], ly["bif"], out_bf16=b["h"], act=ACT_GELU, a_stats=b["st1"], colsum=ly["cs1"], eps=eps, which="ffn1")
-            self._gemm_ln(b["h"], ly["w2"], ly["b2"], out_f32=y2, out_bf16=b["y2b"], residual=y1, r_stats=b["st1"],
-                          r_gamma=ly["g1"], r_beta=ly["b1"], out_stats=b["st2"], eps=eps, which="ffn2")
+                self._gemm_ln(b["ctx"], ly["wo"], ly["bo"], out_f32=y1, out_bf16=b["y1b"], residual=y2, r_stats=stp,
+                              r_gamma=prev["g2"], r_beta=prev["b2n"], out_stats=st1, eps=eps, which="out")
+            self._gemm_ln(b["y1b"], ly["w1f"], ly["bif"], out_bf16=b["h"], act=ACT_GELU, a_stats=st1, colsum=ly["cs1"], eps=eps, which="ffn1")
+            self._gemm_ln(b["h"], ly["w2"], ly["b2"], out_f32=y2, out_bf16=b["y2b"], residual=y1, r_stats=st1,
+                          r_gamma=ly["g1"], r_beta=ly["b1"], out_stats=st2, eps=eps, which="ffn2")
             prev = ly
         self._ln(y2, H, prev["g2"], prev["b2n"], None, b["xf"], M, H, eps)           # last_hidden_state is materialised once (fp32 only: no GEMM reads it)
+        self._guard_pass(st, M)
 
     @torch.no_grad()
     def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, unpad: bool = False, strict: bool = False) -> torch.Tensor:
@@ -365,11 +365,7 @@ class BertTextEncoder(_EncoderBase):
         positions never reach the pooling (text_blocks.py:82-86), so no returned value changes -- bit-identical for
         prefix masks -- while the work drops with the padding fraction.  Shapes vary per batch: not for hipGraph capture."""
         if strict and self.fold_ln:
-            self.guarded = True
-            try:
-                out = self.forward(input_ids, attention_mask, unpad=unpad)
-            finally:
-                self.guarded = False
+            out = self.forward(input_ids, attention_mask, unpad=unpad)
             if not self.check_fold():
                 return out
         if unpad:
@@ -512,9 +508,10 @@ class ClipVisualEncoder(_EncoderBase):
                                "feat": torch.empty(B, self.proj, **f32)}
             p1 = L.lib().ufnd_gemm_bf16_stat_parts(M, H, H)
             p2 = L.lib().ufnd_gemm_bf16_stat_parts(M, H, self.inter)
-            if self.fold_ln and p1 > 0 and p2 > 0 and p1 % 2 == 0 and p2 % 2 == 0:
-                self._bufs[key].update({"st0": torch.zeros(M, 2, 2, **f32), "st1": torch.zeros(M, p1, 2, **f32),
-                                        "st2": torch.zeros(M, p2, 2, **f32)})
+            if self.fold_ln and p1 > 0 and p1 == p2 and p1 % 2 == 0:
+                # st0: the assembled embeddings' statistics; st[2i] / st[2i+1]: layer i's attention / feed-forward half
+                self._bufs[key].update({"st0": torch.zeros(M, 2, 2, **f32), "st": torch.zeros(2 * self.layers, M, p1, 2, **f32)})
+                self._guard_buf(dev)
         return self._bufs[key]
 
     @torch.no_grad()
@@ -544,16 +541,19 @@ class ClipVisualEncoder(_EncoderBase):
         if "st0" in b:
             # pre-LN blocks without LayerNorm kernels: hb is the bf16 rounding of the residual stream xf,
             # st* the row statistics its LayerNorms need (module docstring)
-            eps, stA = self.eps, b["st0"]
-            for ly in p["layers"]:
+            eps, stA, st = self.eps, b["st0"], b["st"]
+            for i, ly in enumerate(p["layers"]):
+                st1, st2 = st[2 * i], st[2 * i + 1]
                 self._gemm_ln(b["hb"], ly["wqkvf"], ly["bqkvf"], out_bf16=b["qkv"], a_stats=stA, colsum=ly["csqkv"], eps=eps, which="qkv")
                 self._attn(b["qkv"], None, b["ctx"], N, T, self.heads)
-                self._gemm_ln(b["ctx"], ly["wo"], ly["bo"], out_f32=b["xf"], out_bf16=b["hb"], residual=b["xf"], out_stats=b["st1"], eps=eps, which="out")
-                self._gemm_ln(b["hb"], ly["w1f"], ly["bif"], out_bf16=b["m"], act=ACT_QUICK_GELU, a_stats=b["st1"], colsum=ly["cs1"], eps=eps, which="ffn1")
-                self._gemm_ln(b["m"], ly["w2"], ly["b2"], out_f32=b["xf"], out_bf16=b["hb"], residual=b["xf"], out_stats=b["st2"], eps=eps, which="ffn2")
-                stA = b["st2"]
+                self._gemm_ln(b["ctx"], ly["wo"], ly["bo"], out_f32=b["xf"], out_bf16=b["hb"], residual=b["xf"], out_stats=st1, eps=eps, which="out")
+                self._gemm_ln(b["hb"], ly["w1f"], ly["bif"], out_bf16=b["m"], act=ACT_QUICK_GELU, a_stats=st1, colsum=ly["cs1"], eps=eps, which="ffn1")
+                self._gemm_ln(b["m"], ly["w2"], ly["b2"], out_f32=b["xf"], out_bf16=b["hb"], residual=b["xf"], out_stats=st2, eps=eps, which="ffn2")
+                stA = st2
             self._ln(b["xf"], T * H, w[V + "post_layernorm.weight"], w[V + "post_layernorm.bias"], b["pooled"], None, N, H, self.eps)
             self._gemm(b["pooled"], p["wproj"], None, out_f32=b["e"])
+            self._guard_pass(b["st0"], M)
+            self._guard_pass(st, M)
             return b["e"], b
         for ly in p["layers"]:
             self._ln(b["xf"], H, ly["g1"], ly["b1"], b["hb"], None, M, H, self.eps)
@@ -574,11 +574,7 @@ class ClipVisualEncoder(_EncoderBase):
         if frames.dim() == 4:
             frames = frames[:, None]
         if strict and self.fold_ln:
-            self.guarded = True
-            try:
-                out = self.forward(frames)
-            finally:
-                self.guarded = False
+            out = self.forward(frames)
             if not self.check_fold():
                 return out
         B, Fr = frames.shape[:2]

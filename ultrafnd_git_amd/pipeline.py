@@ -1,0 +1,451 @@
+"""Step scheduler for `encode_inline`: the native text / visual encoders inside the train step (north_star's "text+vision"
+step; the reference computes the same features offline, src/core_blocks/text_blocks.py:63-106, and trains on the cache,
+src/training/forensic_trainer.py:285-298).
+
+Three HIP streams.  Compute stream (high priority): wait features(i) -> head fwd/bwd(i) -> [gradient exchange(i)] -> clip +
+AdamW(i).  Encoder streams: text(i+1) || visual(i+1), each its own captured hipGraph, enqueued as soon as the head of i is.
+The head, the exchange and the optimizer of step i hide behind the encoders of step i+1; arithmetic and update order are
+those of the plain step (bit-identical: tests).  Encoder lookahead: the frozen encoders run over G consecutive batches per
+pass, the head steps batch by batch.
+
+Input buffers and graphs.  An encoder graph names the addresses it reads.  Inputs the scheduler KNOWS to be persistent -- its
+own lookahead-group buffers, or any batch when `TrainConfig.persistent_inputs` says the loader rotates a few fixed device
+buffers (bench.py: four) -- are read in place by a graph captured for exactly those addresses (no restaging copy: the frames
+alone would be a 19 MB device-to-device copy per step).  Everything else is staged into the encoder's static buffers and
+replayed from ONE graph per shape; `stats` counts both kinds, and a pinned cache that runs full is reported once.
+
+Fold guard.  Every folded encoder pass ends with one guard launch over all of its LayerNorm statistics (encoders.py); after
+every pass the scheduler copies the two guard words to pinned host memory (asynchronously) and looks at the copies that have
+landed before it enqueues the next pass: a trip switches that encoder to materialised LayerNorms from the next pass on and
+drops its graphs.  Nothing synchronises."""
+from __future__ import annotations
+
+import warnings
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+
+class EncoderPipeline:
+    PINNED_GRAPHS = 8      # captured graphs per encoder that read the caller's input buffers in place
+
+    def __init__(self, cfg, device: torch.device, head, reducer, optim, text_encoder, visual_encoder, temporal_net):
+        self.cfg, self.device, self.head, self.reducer, self.optim = cfg, device, head, reducer, optim
+        self.text_encoder, self.visual_encoder, self.temporal_net = text_encoder, visual_encoder, temporal_net
+        self.enc_bufs: Dict[Tuple[int, int, int], dict] = {}
+        self._enc_streams = None
+        self._hp_stream: Optional[torch.cuda.Stream] = None
+        self.slot = 0
+        self.feat_ready = [None, None]
+        self.slot_free = [None, None]
+        self.gslot = 0                      # encoder lookahead: group feature buffers, two slots
+        self.grp_bufs: Dict[Tuple[int, int], dict] = {}
+        self.grp_in: Dict[Tuple[int, int], dict] = {}     # persistent input buffers of the epoch loop's lookahead groups
+        self.grp_ready = [None, None]
+        self.grp_free = [None, None]
+        self.timeline: Optional[list] = None     # tools/step_timeline.py sets a list: (tag, timing event) pairs are appended
+        self._owned: set = set()                 # data_ptr()s of input buffers this scheduler allocated (persistent by construction)
+        self.stats = {"pinned_replays": 0, "staged_replays": 0, "pinned_captures": 0, "pinned_cache_full": 0, "fold_trips": 0}
+        self._warned_full = False
+        self._guard_host: Optional[torch.Tensor] = None
+        self._guard_pending: List[Tuple[torch.cuda.Event, int, str]] = []      # (copy landed, ring index, encoder)
+        self._guard_ring = 0
+        self._enc_version: Dict[str, int] = {}
+
+    # ------------------------------------------------------------------ streams / buffers
+    def _hp(self) -> torch.cuda.Stream:
+        # The head / exchange / optimizer chain is short but serial and shares the GPU with two encoder graphs full of
+        # whole-CU GEMM blocks: on a normal-priority queue every one of its kernels waits for CUs (0.4 ms alone -> 0.8 ms
+        # beside one encoder, 2.3 ms beside both).  It runs on a high-priority stream.
+        if self._hp_stream is None:
+            self._hp_stream = torch.cuda.Stream(device=self.device, priority=-1)
+        return self._hp_stream
+
+    def enc_state(self, B: int, Lq: int, Fr: int, S: int) -> dict:
+        key = (B, Lq, Fr)
+        if key not in self.enc_bufs:
+            dev = self.device
+            self.enc_bufs[key] = {
+                "ids": torch.empty(B, Lq, dtype=torch.int64, device=dev), "mask": torch.empty(B, Lq, dtype=torch.int32, device=dev),
+                "frames": torch.empty(B, Fr, 3, S, S, dtype=torch.float32, device=dev),
+                "text_out": torch.empty(B, 768, dtype=torch.float32, device=dev),
+                "vis_out": torch.empty(B, 512, dtype=torch.float32, device=dev), "g_text": None, "g_vis": None}
+        if self._enc_streams is None:
+            split = self.cfg.cu_split
+            if split:
+                from .streams import MaskedStream, partition_bits
+                bt, bv = partition_bits(split)
+                self._enc_streams = (MaskedStream(self.device, bt), MaskedStream(self.device, bv))
+            else:
+                # (default priorities: a high-priority text stream bought 0.5 % at one GPU and cost 2x under data
+                #  parallelism, where the all-reduce of step i must get CUs while the encoders of step i+1 run)
+                self._enc_streams = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
+        return self.enc_bufs[key]
+
+    def group_bufs(self, GB: int, gslot: int) -> dict:
+        key = (GB, gslot)
+        if key not in self.grp_bufs:
+            self.grp_bufs[key] = {"text": torch.empty(GB, 768, dtype=torch.float32, device=self.device),
+                                  "visual": torch.empty(GB, 512, dtype=torch.float32, device=self.device)}
+        return self.grp_bufs[key]
+
+    def group_inputs(self, ds, rows: torch.Tensor, slot: int) -> dict:
+        """Raw inputs and small per-sample inputs of a lookahead group, gathered into PERSISTENT buffers (one set per group
+        size and slot): the encoder graphs are captured per input address, so a group's inputs must not move."""
+        n = int(rows.numel())
+        key = (n, slot)
+        src = {"input_ids": ds.ids_tok, "attention_mask": ds.mask_tok, "frames": ds.frames, "audio_features": ds.A, "aux": ds.AUX,
+               "label": ds.y, "gnn_feat": ds.G, "temporal_features": ds.U}
+        buf = self.grp_in.get(key)
+        if buf is None:
+            buf = self.grp_in[key] = {k: torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=self.device) for k, t in src.items()}
+            for k in ("input_ids", "attention_mask", "frames"):
+                self._owned.add(buf[k].data_ptr())
+        for k, t in src.items():
+            torch.index_select(t, 0, rows, out=buf[k])
+        out = dict(buf)
+        out["index"] = rows
+        return out
+
+    def mark(self, tag: str, stream) -> None:
+        if self.timeline is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(stream)
+            self.timeline.append((tag, ev))
+
+    def drop_graphs(self, which: str) -> None:
+        """Forget every captured graph of one encoder ("text" / "vis"): its buffers or its LayerNorm form changed."""
+        key = {"text": "g_text", "vis": "g_vis"}[which]
+        for e in self.enc_bufs.values():
+            e[key] = None
+            for k in [k for k in e.get("pinned", {}) if k[0] == which]:
+                del e["pinned"][k]
+
+    # ------------------------------------------------------------------ fold guard (asynchronous)
+    def _guard_poll(self) -> None:
+        """Look at the guard copies that have landed; a trip switches the encoder to materialised LayerNorms (next pass on)."""
+        while self._guard_pending and self._guard_pending[0][0].query():
+            _, slot, which = self._guard_pending.pop(0)
+            enc = self.text_encoder if which == "text" else self.visual_encoder
+            if enc is not None and enc.fold_ln and enc.check_fold(reset=False, ratio=float(self._guard_host[slot])):      # (the device word is a running max: never reset here)
+                self.stats["fold_trips"] += 1
+                self.drop_graphs(which)
+
+    def _guard_record(self, which: str, enc, stream) -> None:
+        """Behind an encoder pass, on its own stream: copy the encoder's guard word to pinned host memory (asynchronously);
+        _guard_poll reads the copies that have completed.  (No extra stream: HIP maps streams onto four hardware queues.)"""
+        if enc is None or not enc.fold_ln or enc._guard is None:
+            return
+        if self._guard_host is None:
+            self._guard_host = torch.zeros(32, dtype=torch.float32).pin_memory()
+        if len(self._guard_pending) >= 24:          # the ring is nearly full: the host is far ahead of the device
+            self._guard_pending[0][0].synchronize()
+            self._guard_poll()
+        slot = self._guard_ring
+        self._guard_ring = (self._guard_ring + 1) % 32
+        self._guard_host[slot:slot + 1].copy_(enc._guard, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        self._guard_pending.append((ev, slot, which))
+
+    def guard_flush(self) -> None:
+        """Wait for every outstanding guard copy and act on it (end of an epoch)."""
+        for ev, _, _ in self._guard_pending:
+            ev.synchronize()
+        self._guard_poll()
+
+    # ------------------------------------------------------------------ encoder graphs
+    def _encode_text(self, e: dict) -> None:
+        e["text_out"].copy_(self.text_encoder(e["ids"], e["mask"]))
+
+    def _encode_vis(self, e: dict) -> None:
+        e["vis_out"].copy_(self.visual_encoder(e["frames"]))
+
+    def _persistent(self, inputs: tuple) -> bool:
+        return bool(self.cfg.persistent_inputs) or all(t.data_ptr() in self._owned for t in inputs)
+
+    def _encode_pinned(self, e: dict, which: str, enc, inputs: tuple, dtypes: tuple, out: torch.Tensor) -> bool:
+        """Encode straight from persistent input buffers into the step's slot buffer, from a graph captured for exactly these
+        addresses.  False when the inputs do not qualify or the cache is full: the caller then stages them into the encoder's
+        static buffers (one graph for any address)."""
+        if not self.cfg.use_graph or not self._persistent(inputs):
+            return False
+        for t, dt in zip(inputs, dtypes):
+            if not (isinstance(t, torch.Tensor) and t.device == self.device and t.dtype == dt and t.is_contiguous()):
+                return False
+        key = (which,) + tuple(t.data_ptr() for t in inputs) + (out.data_ptr(),)
+        cache = e.setdefault("pinned", {})
+        ent = cache.get(key)
+        if ent is None:
+            if sum(1 for k in cache if k[0] == which) >= self.PINNED_GRAPHS:
+                self.stats["pinned_cache_full"] += 1
+                if not self._warned_full:
+                    self._warned_full = True
+                    warnings.warn(f"encoder graph cache full ({self.PINNED_GRAPHS} input buffer sets per encoder): further input buffers are "
+                                  "staged through one device-to-device copy per step (TrainConfig.persistent_inputs promises a small, "
+                                  "fixed set of input buffers)")
+                return False
+            cur = torch.cuda.current_stream(self.device)
+            out.copy_(enc(*inputs))                     # warm-up: packs weights, allocates buffers
+            cur.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=cur, capture_error_mode="thread_local"):
+                out.copy_(enc(*inputs))
+            ent = cache[key] = (g, inputs)              # (the graph names these buffers: keep them alive)
+            self.stats["pinned_captures"] += 1
+        ent[0].replay()
+        self.stats["pinned_replays"] += 1
+        return True
+
+    def _replay_or_capture(self, e: dict, which: str, fn) -> None:
+        """Run `fn(e)` on the current stream: eagerly, or (use_graph) from a graph captured once."""
+        if not self.cfg.use_graph:
+            fn(e)
+            return
+        if e[which] is None:
+            fn(e)                                   # warm-up: packs weights, allocates buffers
+            torch.cuda.current_stream(self.device).synchronize()
+            g = torch.cuda.CUDAGraph()
+            # thread_local: the RCCL watchdog thread may poll events while this thread captures
+            with torch.cuda.graph(g, stream=torch.cuda.current_stream(self.device), capture_error_mode="thread_local"):
+                fn(e)
+            e[which] = g
+        e[which].replay()
+        self.stats["staged_replays"] += 1
+
+    def prefetch_features(self, batch: Dict[str, torch.Tensor], slot: Optional[int] = None,
+                          inputs_ready: Optional[torch.cuda.Event] = None, group: bool = False) -> None:
+        """Encode `batch` on the two encoder streams (text || visual) into input slot `slot` of the step
+        buffers.  Runs concurrently with whatever the compute stream is doing (the fusion head of the
+        previous batch); `feat_ready[slot]` is recorded when both features have landed.
+        group=True: `batch` is a lookahead group (G x batch_size rows, train_group_pipelined): the features go to the group
+        feature buffers of group slot `slot`, and `grp_ready[slot]` is recorded."""
+        self._guard_poll()
+        for which, enc in (("text", self.text_encoder), ("vis", self.visual_encoder)):
+            v = getattr(enc, "weights_version", 0)          # new weights (load_state_dict, .to()): the captured graphs name the old operands
+            if self._enc_version.setdefault(which, v) != v:
+                self._enc_version[which] = v
+                self.drop_graphs(which)
+        slot = (self.gslot if group else self.slot) if slot is None else slot
+        ids, frames = batch["input_ids"], batch["frames"]
+        if frames.dim() == 4:
+            frames = frames[:, None]
+        B, Lq, Fr = int(ids.shape[0]), int(ids.shape[1]), int(frames.shape[1])
+        b = self.group_bufs(B, slot) if group else self.head.bufs(B, True, slot)
+        free = self.grp_free if group else self.slot_free
+        e = self.enc_state(B, Lq, Fr, int(frames.shape[-1]))
+        main = torch.cuda.current_stream(self.device)
+        st, sv = self._enc_streams
+        for strm in (st, sv):
+            # the batch tensors were produced on the compute stream: wait for THEM, not for later work
+            if inputs_ready is not None:
+                strm.wait_event(inputs_ready)
+            else:
+                strm.wait_stream(main)
+            if free[slot] is not None:
+                strm.wait_event(free[slot])   # the head(s) that last read this slot are done with it
+        with torch.cuda.stream(st):
+            self.mark("text0", st)
+            mask = batch["attention_mask"]
+            if not self._encode_pinned(e, "text", self.text_encoder, (ids, mask), (torch.int64, torch.int32), b["text"]):
+                e["ids"].copy_(ids)
+                e["mask"].copy_(mask)
+                self._replay_or_capture(e, "g_text", self._encode_text)
+                b["text"].copy_(e["text_out"])
+            ev_t = torch.cuda.Event()
+            ev_t.record(st)
+            self.mark("text1", st)
+            self._guard_record("text", self.text_encoder, st)
+        with torch.cuda.stream(sv):
+            self.mark("vis0", sv)
+            if not self._encode_pinned(e, "vis", self.visual_encoder, (frames,), (torch.float32,), b["visual"]):
+                e["frames"].copy_(frames)
+                self._replay_or_capture(e, "g_vis", self._encode_vis)
+                b["visual"].copy_(e["vis_out"])
+            ev_v = torch.cuda.Event()
+            ev_v.record(sv)
+            self.mark("vis1", sv)
+            self._guard_record("vis", self.visual_encoder, sv)
+        for t in (ids, batch["attention_mask"], frames):
+            t.record_stream(st)
+            t.record_stream(sv)
+        if group:
+            self.grp_ready[slot] = (ev_t, ev_v)
+        else:
+            self.feat_ready[slot] = (ev_t, ev_v)
+
+    def _temporal(self, b: dict, fallback: torch.Tensor) -> None:
+        if self.temporal_net is not None:      # fakesv_dataset.py:176: U = tsync.align(T, V), written straight into the step's buffer
+            self.temporal_net.align_batch(b["text"], b["visual"], out=b["temporal"])
+        else:
+            b["temporal"].copy_(fallback)
+
+    # ------------------------------------------------------------------ pipelined steps
+    def train_step_pipelined(self, batch: Dict[str, torch.Tensor], next_batch: Optional[Dict[str, torch.Tensor]]) -> dict:
+        """train_step for raw batches whose features were started by prefetch_features():
+          compute stream : wait features(i) -> head fwd/bwd(i) -> [all-reduce(i)] -> clip + AdamW(i)
+          encoder streams: text(i+1) || visual(i+1), launched right after the head of i is enqueued
+        so the head, the exchange and the optimizer of step i all hide behind the (frozen) encoders of
+        step i+1.  Same arithmetic and order of parameter updates as train_step (bit-identical)."""
+        caller = torch.cuda.current_stream(self.device)
+        hp = self._hp()
+        hp.wait_stream(caller)
+        with torch.cuda.stream(hp):
+            out = self._train_step_pipelined(batch, next_batch)
+        caller.wait_stream(hp)
+        return out
+
+    def _train_step_pipelined(self, batch, next_batch) -> dict:
+        from .data import _batch_size
+        B = _batch_size(batch)
+        slot = self.slot
+        b = self.head.bufs(B, True, slot)
+        main = torch.cuda.current_stream(self.device)
+        if self.feat_ready[slot] is None:
+            raise RuntimeError("train_step_pipelined: call prefetch_features(batch) for the first batch")
+        inputs_ready = torch.cuda.Event()
+        inputs_ready.record(main)                  # next_batch (if any) exists on the device by now
+        self.mark("step0", main)
+        for ev in self.feat_ready[slot]:
+            main.wait_event(ev)
+        self.feat_ready[slot] = None
+        self.mark("head0", main)
+        self.head.stage_small_inputs(b, batch, B)
+        self._temporal(b, batch.get("temporal_features") if self.temporal_net is None else None)
+        # With a gradient exchange, the next batch's encoders are enqueued BEFORE the head: the RCCL launches inside
+        # fwd_bwd hold the host until the work they depend on has run (measured: encoders enqueued after a collective
+        # reached the GPU 40 us after the head's end and the step degenerated into head -> encoders -> optimizer in
+        # series).  They read the other input slot, so the order of enqueueing changes no value.
+        early = next_batch is not None and self.reducer.active
+        if early:
+            self.prefetch_features(next_batch, slot ^ 1, inputs_ready)
+        self.head.fwd_bwd(b, B)
+        done = torch.cuda.Event()
+        done.record(main)
+        self.slot_free[slot] = done
+        self.mark("head1", main)
+        if next_batch is not None and not early:
+            self.prefetch_features(next_batch, slot ^ 1, inputs_ready)
+        self.reducer.finish()
+        self.mark("reduce1", main)
+        self.optim.clip_and_step()
+        self.mark("opt1", main)
+        self.slot ^= 1
+        return {"loss": self.optim.state.float_view("loss"), "probs": b["probs"], "y": b["label"],
+                "forensic": b["forensic"], "logits": b["logits"]}
+
+    def train_group_pipelined(self, group: Dict[str, torch.Tensor], next_group: Optional[Dict[str, torch.Tensor]],
+                              steps: Optional[int] = None, on_step=None) -> dict:
+        """`steps` (default: all G) optimizer steps over a lookahead group: a dict of raw inputs with G x batch_size rows whose
+        features prefetch_features(group=True) has started.  The encoders are frozen (as in the reference, where the features
+        are a precomputed cache), so encoding G batches in ONE pass changes no value -- a row's features do not depend on the
+        batch it is encoded in, bit for bit (test) -- while every GEMM launch gets G times the rows: fewer, larger launches.
+        The head, the loss, the gradient exchange, the clip and AdamW run per batch of batch_size rows, in order, exactly as
+        train_step does: G optimizer steps.  The next group's encoders are enqueued behind the first head.
+        `on_step(b)` (optional) is called after every optimizer step with the step's static buffers (the epoch loop clones
+        what its metrics need)."""
+        caller = torch.cuda.current_stream(self.device)
+        hp = self._hp()
+        hp.wait_stream(caller)
+        with torch.cuda.stream(hp):
+            out = self._train_group_pipelined(group, next_group, steps, on_step)
+        caller.wait_stream(hp)
+        return out
+
+    def _train_group_pipelined(self, group, next_group, steps, on_step=None) -> dict:
+        B = int(self.cfg.batch_size)
+        GB = int(group["input_ids"].shape[0])
+        if GB % B:
+            raise RuntimeError(f"lookahead group of {GB} rows is not a multiple of batch_size {B}")
+        G = GB // B
+        steps = G if steps is None else int(steps)
+        gslot = self.gslot
+        grp = self.group_bufs(GB, gslot)
+        main = torch.cuda.current_stream(self.device)
+        if self.grp_ready[gslot] is None:
+            raise RuntimeError("train_group_pipelined: call prefetch_features(group, group=True) for the first group")
+        inputs_ready = torch.cuda.Event()
+        inputs_ready.record(main)
+        self.mark("step0", main)
+        for ev in self.grp_ready[gslot]:
+            main.wait_event(ev)
+        self.grp_ready[gslot] = None
+        self.mark("head0", main)
+        b = self.head.bufs(B, True, 0)
+        losses = []
+        started_next = next_group is None
+        for k in range(steps):
+            self.head.stage_group_rows(b, group, grp, k, B)
+            self._temporal(b, group["temporal_features"][k * B:(k + 1) * B] if self.temporal_net is None else None)
+            if not started_next and self.reducer.active:      # (before the collectives: see _train_step_pipelined)
+                self.prefetch_features(next_group, gslot ^ 1, inputs_ready, group=True)
+                started_next = True
+            self.head.fwd_bwd(b, B)
+            if not started_next:
+                self.prefetch_features(next_group, gslot ^ 1, inputs_ready, group=True)
+                started_next = True
+            self.reducer.finish()
+            self.optim.clip_and_step()
+            losses.append(self.optim.state.float_view("loss").clone())
+            if on_step is not None:
+                on_step(b)
+        done = torch.cuda.Event()
+        done.record(main)
+        self.grp_free[gslot] = done
+        self.mark("opt1", main)
+        self.gslot ^= 1
+        return {"loss": self.optim.state.float_view("loss"), "losses": losses, "probs": b["probs"], "y": b["label"],
+                "forensic": b["forensic"], "logits": b["logits"]}
+
+    # ------------------------------------------------------------------ instrumentation (bench.py's roofline leg)
+    def measure_gemm_time(self, batch: Dict[str, torch.Tensor], steps: int = 3) -> Tuple[float, int]:
+        """(ms of ufnd_gemm_bf16 per step, launches per step): HIP events recorded on the launch
+        stream around every GEMM launch of both encoders (an instrumented pass, not the timed one)."""
+        events: List[Tuple[torch.cuda.Event, torch.cuda.Event]] = []
+        shapes: List[Tuple[int, int, int]] = []
+        originals = []
+        passes: List[Tuple[int, int]] = []
+        for enc in (self.text_encoder, self.visual_encoder):
+            for name in ("_gemm", "_gemm_ln", "_qkv_attn"):       # plain, LayerNorm-aware and fused-attention entries: one kernel family
+                orig = getattr(enc, name)
+
+                def timed(A, W, *a, _orig=orig, **kw):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    _orig(A, W, *a, **kw)
+                    e1.record()
+                    events.append((e0, e1))
+                    shapes.append((int(A.shape[0]), int(W.shape[0]), int(W.shape[1])))
+                originals.append((enc, name, orig))
+                setattr(enc, name, timed)
+        try:
+            for _ in range(steps):
+                # park the GPU behind a ~12 ms spin so the host has every launch and event of the pass queued
+                # before the GPU reaches them: event deltas then measure GPU time, not host enqueue latency
+                for enc, args in ((self.text_encoder, (batch["input_ids"], batch["attention_mask"])), (self.visual_encoder, (batch["frames"],))):
+                    torch.cuda._sleep(24_000_000)
+                    mark = len(events)
+                    enc(*args)
+                    passes.append((mark, len(events)))
+            torch.cuda.synchronize(self.device)
+        finally:
+            for enc, name, orig in originals:
+                setattr(enc, name, orig)
+        # An event costs the queue a marker packet.  Its price is taken IN SITU: where two GEMMs follow each other
+        # with nothing in between, (end event of the first -> start event of the second) is exactly one
+        # marker-to-marker interval of the busy queue; the lower quartile of all such gaps of a pass is that price
+        # (the other gaps contain an attention / LayerNorm kernel).  launch duration = (end - start) - price.
+        gaps = []
+        for lo, hi in passes:
+            gaps += [events[k][1].elapsed_time(events[k + 1][0]) for k in range(lo, hi - 1)]
+        gaps.sort()
+        marker = gaps[len(gaps) // 4] if gaps else 0.0
+        self.last_marker_us = marker * 1e3
+        total = sum(max(0.0, e0.elapsed_time(e1) - marker) for e0, e1 in events)
+        self.last_raw_interval_us = sum(e0.elapsed_time(e1) for e0, e1 in events) / max(1, len(events)) * 1e3
+        self.last_gemm_by_shape = {}
+        for (e0, e1), shp in zip(events, shapes):
+            d = self.last_gemm_by_shape.setdefault("x".join(map(str, shp)), [0, 0.0])
+            d[0] += 1
+            d[1] += max(0.0, e0.elapsed_time(e1) - marker)
+        return total / steps, len(events) // steps

@@ -9,7 +9,6 @@ L2 serves both chains and a text GEMM of 192 tiles is exactly one round on its s
 from __future__ import annotations
 
 import ctypes as C
-import os
 from typing import List, Sequence
 
 import torch
@@ -18,7 +17,7 @@ from . import _lib as L
 
 # How bit b of a CU mask maps to hardware on gfx950 (measured with tools/cu_mask_probe.py):
 #   "striped": bit b -> XCD b % 8, CU b // 8 of that XCD;  "block": bit b -> XCD b // 32, CU b % 32.
-LAYOUT = os.environ.get("UFND_CU_MASK_LAYOUT", "striped")
+LAYOUT = "striped"
 XCDS, CUS_PER_XCD = 8, 32
 
 

@@ -93,8 +93,10 @@ class TemporalSyncNet(nn.Module):
         return self._packed
 
     @torch.no_grad()
-    def align_batch(self, text: torch.Tensor, visual: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
-        """(B,in_dim), (B,Dv) device tensors -> (B,out_dim) device tensor (written into `out` when given)."""
+    def align_batch(self, text: torch.Tensor, visual: torch.Tensor, out: torch.Tensor = None, training: bool = None) -> torch.Tensor:
+        """(B,in_dim), (B,Dv) device tensors -> (B,out_dim) device tensor (written into `out` when given).
+        `training` overrides `self.training` for this call (the trainer evaluates its validation / test splits with the
+        deterministic projection whatever mode the module was left in)."""
         dev = self.proj[0].weight.device
         if dev.type != "cuda":
             raise L.UltrafndHipError("TemporalSyncNet runs on a HIP device only: call .to('cuda') (no CPU fallback)")
@@ -110,7 +112,7 @@ class TemporalSyncNet(nn.Module):
             out = torch.empty(B, self.out_dim, dtype=torch.float32, device=dev)
         elif tuple(out.shape) != (B, self.out_dim) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev:
             raise RuntimeError(f"align_batch: out must be a contiguous fp32 ({B},{self.out_dim}) tensor on {dev}")
-        p = float(self.proj[2].p) if self.training else 0.0
+        p = float(self.proj[2].p) if (self.training if training is None else training) else 0.0
         st = None
         if p > 0.0:                  # device-resident counter: every call draws a fresh mask (stream-ordered, no host copy)
             if self._align_state is None or self._align_state.device != dev:
