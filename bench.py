@@ -222,6 +222,8 @@ def main():
                          "the head, the exchange and the optimizer always step batch by batch")
     ap.add_argument("--no-lookahead-compare", action="store_true", help="skip the lookahead-1 comparison leg")
     ap.add_argument("--no-fuse-attn", action="store_true", help="text encoder: Q/K/V projection and attention as two launches per layer")
+    ap.add_argument("--residual-dtype", choices=("fp32", "bf16"), default="bf16",
+                    help="encoders' residual stream: fp32 beside the bf16 operands, or the bf16 rounding itself (encoders.py)")
     ap.add_argument("--head-only", action="store_true",
                     help="secondary measurement: the reference's actual training mode (cached features, no encoders in the step)")
     ap.add_argument("--dry-launch", action="store_true", help="--gpus N > 1 started plainly: print the torchrun command it would start, start nothing")
@@ -296,8 +298,8 @@ def main():
         return
     global SEQ_LEN, FRAMES
     SEQ_LEN, FRAMES = args.seq_len, args.frames       # (defaults = the headline configuration, BASELINE configs[1])
-    tenc = BertTextEncoder(fold_ln=not args.no_fold_ln).to(dev)            # BERT-base geometry, random init (no checkpoints offline)
-    venc = ClipVisualEncoder(fold_ln=not args.no_fold_ln).to(dev)          # CLIP ViT-B/32 geometry, random init
+    tenc = BertTextEncoder(fold_ln=not args.no_fold_ln, residual_dtype=args.residual_dtype).to(dev)    # BERT-base geometry, random init (no checkpoints offline)
+    venc = ClipVisualEncoder(fold_ln=not args.no_fold_ln, residual_dtype=args.residual_dtype).to(dev)  # CLIP ViT-B/32 geometry, random init
     split = None
     if args.cu_split and args.cu_split != "0":
         split = tuple(int(x) for x in args.cu_split.split(","))
@@ -434,7 +436,7 @@ def main():
                                     "once, inside the timed region; features are bit-identical to one-batch passes), one optimizer step per batch" if G > 1 else ""),
                        "per_gpu_batch": B, "global_batch": world * B, "encoder_lookahead_batches": G,
                        "seq_len": SEQ_LEN, "frames": FRAMES, "image": IMAGE, "parallelism": f"dp{world}",
-                       "encoder_dtype": "bf16 operands / fp32 accumulate", "head_dtype": "fp32", "hip_graph": not args.no_graph,
+                       "encoder_dtype": "bf16 operands / fp32 accumulate", "residual_stream": args.residual_dtype, "head_dtype": "fp32", "hip_graph": not args.no_graph,
                        "weights": "random init of the named architectures"},
             "timing": {"what": f"median of {len(blocks)} back-to-back blocks of {args.steps} steps, each between barrier + synchronize fences",
                        "ms_per_step_blocks": [round(x / args.steps * 1e3, 4) for x in blocks],

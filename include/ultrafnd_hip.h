@@ -221,6 +221,8 @@ int ufnd_clip_adamw_step(float* param, const float* grad, float* exp_avg, float*
 #define UFND_ACT_NONE 0
 #define UFND_ACT_GELU 1       /* exact erf GELU (BERT intermediate) */
 #define UFND_ACT_QUICK_GELU 2 /* x * sigmoid(1.702 x) (CLIP MLP) */
+#define UFND_ACT_GELU_BWD 3       /* ufnd_gemm_bf16_dgrad only: out = acc * GELU'(aux) */
+#define UFND_ACT_QUICK_GELU_BWD 4 /* ufnd_gemm_bf16_dgrad only: out = acc * quick_GELU'(aux) */
 
 /* fp32 -> bf16 (round to nearest even); used once per weight tensor. */
 int ufnd_cast_bf16(const float* src, void* dst_bf16, size_t n, void* stream);
@@ -275,6 +277,12 @@ typedef struct ufnd_gemm_ln {
   float a_eps, r_eps;
   int width;
   int tile_cfg; /* < 0: automatic; otherwise a LayerNorm-aware tile id (ufnd_gemm_bf16_tile_info) */
+  /* bf16 residual stream (ABI v3): the residual operand as (M, ldrb) bf16 rows -- the rounding the producing GEMM already
+   * wrote for its consumer -- instead of the fp32 `residual` argument (exclusive).  With it and out_f32 = NULL a residual
+   * GEMM moves 2 + 2 B per element of the stream instead of 4 + 4 + 2; the stream then carries 8 significant bits per
+   * layer (statistics are still taken from the fp32 sums before rounding). */
+  const void* residual_bf16;
+  int ldrb;
 } ufnd_gemm_ln;
 int ufnd_gemm_bf16_ln(const void* A, const void* W, const float* bias, const float* residual, void* out_bf16,
                       float* out_f32, int M, int N, int K, int lda, int ldw, int ldr, int ldo, int ldf, int act,
@@ -506,6 +514,66 @@ int ufnd_fusion_gnn_input_grad(const ufnd_dims* d, const ufnd_fusion_params* p, 
 int ufnd_stream_create_cu_mask(const uint32_t* mask_words, int n_words, void** stream_out);
 int ufnd_stream_destroy(void* stream);
 int ufnd_device_cu_count(void);
+
+/* ====================================================================================
+ * Tier-B backward (ABI v3; SURVEY.md 8b's *_bwd list).  The reference never trains its encoders
+ * (src/core_blocks/text_blocks.py:52 `.eval()`, :63 `inference_mode`), so no reference interface is replaced here: these
+ * are the backward forms of the forward entry points above, for TrainConfig.train_encoders.  Parity: torch autograd over
+ * oracle/encoders_ref.py, itself checked against the installed third-party classes ("parity unpinned by the reference").
+ * bf16 operands, fp32 accumulation; parameter gradients are written in fp32; nothing uses atomics (results are
+ * run-to-run identical).
+ * ================================================================================== */
+
+/* out (M, N) = dY (M, K) x Wt (N, K)^T [x act'(aux)] [+ residual]: the data gradient of y = x W^T through the TRANSPOSED
+ * weight copy Wt = W^T (N = in_features rows of K = out_features).  act = UFND_ACT_GELU_BWD / UFND_ACT_QUICK_GELU_BWD
+ * multiplies by the activation's derivative at the pre-activations aux (M, ldaux) bf16 (fused dgrad through FFN1's
+ * activation); residual (M, ldr) fp32 adds the gradient arriving over the residual branch.  aux and residual are exclusive. */
+int ufnd_gemm_bf16_dgrad(const void* dY, const void* Wt, const float* residual, const void* aux, void* out_bf16, float* out_f32,
+                         int M, int N, int K, int lda, int ldw, int ldr, int ldaux, int ldo, int ldf, int act, void* stream);
+
+/* dW (n_out, k_in) fp32 [+]= dYt (n_out, tokens) x Xt (k_in, tokens)^T: the weight gradient of y = x W^T from the transposed
+ * activations (ufnd_transpose_bf16; `tokens` padded to a multiple of 64 with zero columns).  The token range is cut into
+ * slices (grid = tiles x slices, fp32 partial slabs in `workspace`), a reduce pass adds the slabs in slice order. */
+size_t ufnd_gemm_bf16_wgrad_workspace_floats(int n_out, int k_in, int tokens);
+int ufnd_gemm_bf16_wgrad(const void* dYt, const void* Xt, float* dW, int n_out, int k_in, int tokens, int lda, int ldb, int ldw,
+                         float* workspace, int accumulate, void* stream);
+
+/* dst (cols, ldd) bf16 = src (rows, lds)^T, columns rows..rows_pad-1 zero; src bf16, or fp32 (src_is_f32: cast on the way --
+ * weight masters to transposed operand copies).  colsum != NULL (bf16 sources): colsum (cols) [+]= the column sums of src
+ * (bias gradients: db = sum over tokens of dy), two-stage through colsum_ws (ufnd_transpose_colsum_workspace_floats). */
+size_t ufnd_transpose_colsum_workspace_floats(int rows_pad, int cols);
+int ufnd_transpose_bf16(const void* src, int src_is_f32, int rows, int cols, int lds, void* dst, int ldd, int rows_pad, float* colsum,
+                        float* colsum_ws, int colsum_accumulate, void* stream);
+
+/* ufnd_attention_bf16 that also keeps lse (B L, heads) fp32: each query's log-sum-exp of its scaled, masked scores in the
+ * log2 domain -- what ufnd_attention_bf16_bwd recomputes P from. */
+int ufnd_attention_bf16_lse(const void* qkv, const int32_t* key_mask, void* ctx, float* lse, int B, int L, int heads, void* stream);
+/* dqkv (B L, 3H) bf16 = the gradients of the fused q | k | v rows, from dctx (B L, H) bf16, the forward's qkv, ctx and lse.
+ * workspace: ufnd_attention_bwd_workspace_floats floats (delta = rowsum(dO o O)).  Three launches (delta; dQ; dK and dV). */
+size_t ufnd_attention_bwd_workspace_floats(int B, int L, int heads);
+int ufnd_attention_bf16_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, const int32_t* key_mask, void* dqkv,
+                            float* workspace, int B, int L, int heads, void* stream);
+
+/* LayerNorm backward: dx = rstd (g - mean(g) - xh mean(g xh)) [+ add], g = dy gamma, xh = (x - mean) rstd, from the LayerNorm's
+ * INPUT x (M rows of stride ldx); dx as fp32 and / or bf16 (stride lddx).  dgamma / dbeta (H) [+]= their row sums (two-stage,
+ * through `workspace`: ufnd_layernorm_bwd_workspace_floats); both may be NULL (then workspace may be too). */
+size_t ufnd_layernorm_bwd_workspace_floats(int M, int H);
+int ufnd_layernorm_bwd(const float* x, int ldx, const float* gamma, const float* dy, int lddy, const float* add, int ldadd, float* dx_f32,
+                       void* dx_bf16, int lddx, float* dgamma, float* dbeta, float* workspace, int accumulate, int M, int H, float eps,
+                       void* stream);
+
+/* ufnd_masked_meanpool_l2 backward: dhidden (B L, H) from dfeat (B, H) and the forward's inputs. */
+int ufnd_masked_meanpool_l2_bwd(const float* hidden, const int32_t* mask, const float* dfeat, float* dhidden, int B, int L, int H, void* stream);
+/* ufnd_l2norm_frames backward: de (B F, D) from dfeat (B, D) and the forward's input e. */
+int ufnd_l2norm_frames_bwd(const float* e, const float* dfeat, float* de, int B, int F, int D, void* stream);
+/* BERT embeddings backward from ds (B L, H) = the gradient of the summed embeddings (ufnd_bert_embed with gamma = beta = NULL
+ * returns those sums; their LayerNorm is ufnd_layernorm / ufnd_layernorm_bwd): dword (vocab, H), dpos (max_pos, H),
+ * dtype (type_vocab, H) are overwritten. */
+int ufnd_bert_embed_bwd(const int64_t* ids, const float* ds, float* dword, float* dpos, float* dtype, int B, int L, int H, int vocab,
+                        int max_pos, int type_vocab, void* stream);
+/* ViT token assembly backward from ds (N (P + 1), H): dcls (H), dpos (P + 1, H) overwritten; dpe (N P, H) bf16 = the patch rows
+ * (the `patch_embed_bwd` of SURVEY 8b is ufnd_gemm_bf16_wgrad on dpe and the patch matrix). */
+int ufnd_vit_assemble_bwd(const float* ds, float* dcls, float* dpos, void* dpe_bf16, int N, int P, int H, void* stream);
 
 #ifdef __cplusplus
 }

@@ -143,8 +143,9 @@ def _mha(x, wq, bq, wk, bk, wv, bv, heads: int, add_mask: Optional[torch.Tensor]
 
 
 def bert_last_hidden_state(w: Dict[str, torch.Tensor], input_ids, attention_mask,
-                           heads: int = 12, eps: float = 1e-12) -> torch.Tensor:
-    """BertModel(...).last_hidden_state -- text_blocks.py:79."""
+                           heads: int = 12, eps: float = 1e-12, collect: Optional[dict] = None) -> torch.Tensor:
+    """BertModel(...).last_hidden_state -- text_blocks.py:79.  collect (optional dict): filled with the hidden states after
+    each layer, {1: ..., 2: ...} (BertModel's output_hidden_states[1:]), for per-layer localisation in the tests."""
     B, L = input_ids.shape
     H = w["embeddings.word_embeddings.weight"].shape[1]
     x = (w["embeddings.word_embeddings.weight"][input_ids]
@@ -166,6 +167,8 @@ def bert_last_hidden_state(w: Dict[str, torch.Tensor], input_ids, attention_mask
         y = F.linear(h, w[P + "output.dense.weight"], w[P + "output.dense.bias"])
         x = F.layer_norm(y + x, (H,), w[P + "output.LayerNorm.weight"], w[P + "output.LayerNorm.bias"], eps)
         i += 1
+        if collect is not None:
+            collect[i] = x
     return x
 
 
@@ -192,8 +195,9 @@ def field_mean_l2(parts: torch.Tensor) -> torch.Tensor:
 # CLIP ViT-B/32 visual encoder (pre-LN)
 # --------------------------------------------------------------------------
 def vit_pooled(w: Dict[str, torch.Tensor], pixels: torch.Tensor, heads: int = 12,
-               eps: float = 1e-5) -> torch.Tensor:
-    """CLIPVisionModel(...).pooler_output: (N,3,224,224) -> (N,768)."""
+               eps: float = 1e-5, collect: Optional[dict] = None) -> torch.Tensor:
+    """CLIPVisionModel(...).pooler_output: (N,3,224,224) -> (N,768).  collect (optional dict): the residual stream after each
+    layer, {1: ..., 2: ...} (CLIPVisionModel's hidden_states[1:])."""
     V = "vision_model."
     pw = w[V + "embeddings.patch_embedding.weight"]
     H, patch = pw.shape[0], pw.shape[-1]
@@ -215,6 +219,8 @@ def vit_pooled(w: Dict[str, torch.Tensor], pixels: torch.Tensor, heads: int = 12
         h = h * torch.sigmoid(1.702 * h)                               # quick_gelu
         x = x + F.linear(h, w[P + "mlp.fc2.weight"], w[P + "mlp.fc2.bias"])
         i += 1
+        if collect is not None:
+            collect[i] = x
     return F.layer_norm(x[:, 0], (H,), w[V + "post_layernorm.weight"], w[V + "post_layernorm.bias"], eps)
 
 

@@ -67,7 +67,7 @@ class GemmLn(C.Structure):
     """ufnd_gemm_ln: the LayerNorm extras of ufnd_gemm_bf16_ln."""
     _fields_ = [("a_stats", _FP), ("colsum", _FP), ("r_stats", _FP), ("r_gamma", _FP), ("r_beta", _FP), ("out_stats", _FP),
                 ("a_parts", C.c_int), ("r_parts", C.c_int), ("a_eps", C.c_float), ("r_eps", C.c_float), ("width", C.c_int),
-                ("tile_cfg", C.c_int)]
+                ("tile_cfg", C.c_int), ("residual_bf16", _FP), ("ldrb", C.c_int)]
 
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
@@ -145,10 +145,27 @@ def _declare_encoders(lib: C.CDLL) -> None:
         "ufnd_field_mean_l2": [P, P, P, I, I, I, P],
         "ufnd_temporal_align": [P] * 8 + [I] * 5 + [F, P, P],
     }
+    sigs.update({
+        "ufnd_gemm_bf16_dgrad": [P] * 6 + [I] * 10 + [P],
+        "ufnd_gemm_bf16_wgrad": [P, P, P, I, I, I, I, I, I, P, I, P],
+        "ufnd_transpose_bf16": [P, I, I, I, I, P, I, I, P, P, I, P],
+        "ufnd_attention_bf16_lse": [P, P, P, P, I, I, I, P],
+        "ufnd_attention_bf16_bwd": [P, P, P, P, P, P, P, I, I, I, P],
+        "ufnd_layernorm_bwd": [P, I, P, P, I, P, I, P, P, I, P, P, P, I, I, I, F, P],
+        "ufnd_masked_meanpool_l2_bwd": [P, P, P, P, I, I, I, P],
+        "ufnd_l2norm_frames_bwd": [P, P, P, I, I, I, P],
+        "ufnd_bert_embed_bwd": [P, P, P, P, P, I, I, I, I, I, I, P],
+        "ufnd_vit_assemble_bwd": [P, P, P, P, I, I, I, P],
+    })
     for name, argtypes in sigs.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = I
+    for name, argtypes in (("ufnd_gemm_bf16_wgrad_workspace_floats", [I, I, I]), ("ufnd_transpose_colsum_workspace_floats", [I, I]),
+                           ("ufnd_attention_bwd_workspace_floats", [I, I, I]), ("ufnd_layernorm_bwd_workspace_floats", [I, I])):
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = S
     D = C.c_double
     lib.ufnd_ocr_adjacency.argtypes = [P, P, I, D, P, I, P]
     lib.ufnd_ocr_adjacency.restype = I

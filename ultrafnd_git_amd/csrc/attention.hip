@@ -37,7 +37,7 @@ __device__ __forceinline__ bf16x8 k_frag(const char* tile, int row, int chunk) {
 // samples in flight with 2-wave workgroups (a block is one dependent chain: loads -> S -> softmax -> O -> store).
 template <int KB, int NW = 4>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 2 ? 3 : 2))) void attention_kernel(const __bf16* qkv, const int32_t* mask, __bf16* ctx, int L,
-                                                        int heads, float scale_log2e, const int32_t* cu) {
+                                                        int heads, float scale_log2e, const int32_t* cu, float* lse) {
   __shared__ __attribute__((aligned(16))) char ks[KB * 128];
   __shared__ __attribute__((aligned(16))) char vs[KB * 128];
   __shared__ __attribute__((aligned(16))) float kbias[KB];
@@ -173,6 +173,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 2
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
+    // training forwards keep the query's log-sum-exp (log2 domain, as the scores above): the backward recomputes P from it
+    if (lse && g == 0 && qrow[qt] < L) lse[(tok0 + qrow[qt]) * heads + h] = m_run[qt] + log2f(l);
     if (qrow[qt] < L) {
       __bf16* dst = ctx + (tok0 + qrow[qt]) * H + h * 64 + 4 * g;
 #pragma unroll
@@ -187,8 +189,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 2
 
 }  // namespace
 
+extern "C" int ufnd_attention_bf16_lse(const void* qkv, const int32_t* key_mask, void* ctx, float* lse, int B, int L, int heads,
+                                       void* stream_);
 extern "C" int ufnd_attention_bf16(const void* qkv, const int32_t* key_mask, void* ctx, int B, int L, int heads,
                                    void* stream_) {
+  return ufnd_attention_bf16_lse(qkv, key_mask, ctx, nullptr, B, L, heads, stream_);
+}
+
+extern "C" int ufnd_attention_bf16_lse(const void* qkv, const int32_t* key_mask, void* ctx, float* lse, int B, int L, int heads,
+                                       void* stream_) {
   UFND_REQUIRE(qkv && ctx, "attention: null operand");
   UFND_REQUIRE(B >= 1 && L >= 1 && L <= 4096 && heads >= 1 && heads <= 64, "attention: B=%d L=%d heads=%d", B, L, heads);
   UFND_REQUIRE(ufnd_aligned(qkv, 16) && ufnd_aligned(ctx, 16), "attention: 16-B alignment required");
@@ -196,10 +205,10 @@ extern "C" int ufnd_attention_bf16(const void* qkv, const int32_t* key_mask, voi
   const float scale_log2e = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) * log2(e)
   if (L <= 64)
     hipLaunchKernelGGL((attention_kernel<64, 2>), dim3(1, heads, B), dim3(128), 0, (hipStream_t)stream_,
-                       (const __bf16*)qkv, key_mask, (__bf16*)ctx, L, heads, scale_log2e, (const int32_t*)nullptr);
+                       (const __bf16*)qkv, key_mask, (__bf16*)ctx, L, heads, scale_log2e, (const int32_t*)nullptr, lse);
   else
     hipLaunchKernelGGL((attention_kernel<64, 4>), dim3(ufnd_cdiv(L, QB), heads, B), dim3(256), 0, (hipStream_t)stream_,
-                       (const __bf16*)qkv, key_mask, (__bf16*)ctx, L, heads, scale_log2e, (const int32_t*)nullptr);
+                       (const __bf16*)qkv, key_mask, (__bf16*)ctx, L, heads, scale_log2e, (const int32_t*)nullptr, lse);
   UFND_CHECK_LAUNCH();
   return UFND_OK;
 }
@@ -212,7 +221,7 @@ extern "C" int ufnd_attention_bf16_varlen(const void* qkv, const int32_t* cu_seq
   UFND_REQUIRE(ufnd_aligned(qkv, 16) && ufnd_aligned(ctx, 16), "attention_varlen: 16-B alignment required");
   const float scale_log2e = 0.125f * 1.44269504088896340736f;
   hipLaunchKernelGGL((attention_kernel<64, 4>), dim3(ufnd_cdiv(max_len, QB), heads, B), dim3(256), 0, (hipStream_t)stream_,
-                     (const __bf16*)qkv, (const int32_t*)nullptr, (__bf16*)ctx, max_len, heads, scale_log2e, cu_seqlens);
+                     (const __bf16*)qkv, (const int32_t*)nullptr, (__bf16*)ctx, max_len, heads, scale_log2e, cu_seqlens, (float*)nullptr);
   UFND_CHECK_LAUNCH();
   return UFND_OK;
 }

@@ -47,6 +47,10 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return cdf + x * pdf;
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float quick_gelu_grad_f(float x) {      // d/dx [x sigmoid(1.702 x)]
+  const float s = 1.0f / (1.0f + __expf(-1.702f * x));
+  return s * (1.0f + 1.702f * x * (1.0f - s));
+}
 // bf16-output epilogues.  Contraction is switched OFF inside them (HIP's __fmul_rn / __fadd_rn are plain
 // operators, which the compiler may still fuse differently per kernel instantiation) and every fused
 // multiply-add is spelled out: every GEMM tile shape must emit the same operation sequence, so that a

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void bert_embed_kernel(const int64_t* ids, con
     const int col = 4 * lane + 256 * i;
     v[i] = ld4(word + (size_t)id * H + col) + ld4(pos + (size_t)l * H + col) + ld4(type0 + col);
   }
-  ln_row<NI>(v, H, eps, gamma, beta, lane);
+  if (gamma) ln_row<NI>(v, H, eps, gamma, beta, lane);      // (gamma == NULL: the raw sums, for training forwards that keep them)
   store_row<NI>(v, ob, of, row, H, lane);
 }
 
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void vit_assemble_kernel(const float* pe, cons
     const f32x4 base = (t == 0) ? ld4(cls + col) : ld4(pe + ((size_t)n * P + (t - 1)) * H + col);
     v[i] = base + ld4(pos + (size_t)t * H + col);
   }
-  ln_row<NI>(v, H, eps, gamma, beta, lane);
+  if (gamma) ln_row<NI>(v, H, eps, gamma, beta, lane);      // (gamma == NULL: the raw sums)
   store_row<NI>(v, ob, of, row, H, lane);
   if (stats) row_stats<NI>(v, stats, row, lane);
 }
@@ -302,7 +302,7 @@ extern "C" int ufnd_layernorm(const float* x, int ldx, const float* gamma, const
 extern "C" int ufnd_bert_embed(const int64_t* ids, const float* word, const float* pos, const float* type0,
                                const float* gamma, const float* beta, void* x_bf16, float* x_f32, int B, int L, int H,
                                int vocab, float eps, void* stream_) {
-  UFND_REQUIRE(ids && word && pos && type0 && gamma && beta && (x_bf16 || x_f32), "bert_embed: null argument");
+  UFND_REQUIRE(ids && word && pos && type0 && ((gamma && beta) || (!gamma && !beta)) && (x_bf16 || x_f32), "bert_embed: null argument");
   UFND_REQUIRE(h_ok(H) && B >= 1 && L >= 1 && vocab >= 1, "bert_embed: B=%d L=%d H=%d vocab=%d", B, L, H, vocab);
   UFND_REQUIRE(ufnd_aligned(word, 16) && ufnd_aligned(pos, 16) && ufnd_aligned(type0, 16), "bert_embed: alignment");
   const int M = B * L;
@@ -361,7 +361,7 @@ extern "C" int ufnd_vit_patchify(const float* frames, void* patches, int N, int 
 extern "C" int ufnd_vit_assemble(const float* patch_emb, const float* cls, const float* pos, const float* gamma,
                                  const float* beta, float* x_f32, void* x_bf16, float* stats, int N, int P, int H, float eps,
                                  void* stream_) {
-  UFND_REQUIRE(patch_emb && cls && pos && gamma && beta && x_f32 && N >= 1 && P >= 1, "vit_assemble: null argument");
+  UFND_REQUIRE(patch_emb && cls && pos && ((gamma && beta) || (!gamma && !beta)) && x_f32 && N >= 1 && P >= 1, "vit_assemble: null argument");
   UFND_REQUIRE(h_ok(H), "vit_assemble: H=%d", H);
   const int M = N * (P + 1);
   UFND_REQUIRE(!stats || ufnd_aligned(stats, 16), "vit_assemble: stats alignment");

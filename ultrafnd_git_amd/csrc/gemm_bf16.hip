@@ -70,6 +70,8 @@ extern "C" int ufnd_gemm_bf16_ln(const void* A, const void* W, const float* bias
   UFND_REQUIRE(!bias || ufnd_aligned(bias, 16), "gemm_bf16_ln: bias must be 16-B aligned");
   UFND_REQUIRE(act >= 0 && act <= 2, "gemm_bf16_ln: act=%d", act);
   UFND_REQUIRE(!(ln->a_stats && ln->r_stats), "gemm_bf16_ln: a_stats and r_stats are mutually exclusive");
+  UFND_REQUIRE(!(residual && ln->residual_bf16), "gemm_bf16_ln: residual (fp32) and residual_bf16 are mutually exclusive");
+  UFND_REQUIRE(!ln->residual_bf16 || (ln->ldrb % 8 == 0 && ln->ldrb >= N && ufnd_aligned(ln->residual_bf16, 16)), "gemm_bf16_ln: residual_bf16 alignment");
   UFND_REQUIRE(ln->a_stats || act == UFND_ACT_NONE, "gemm_bf16_ln: an activation is only fused together with a folded LayerNorm (a_stats)");
   UFND_REQUIRE(ln->width > 0, "gemm_bf16_ln: width (the LayerNorm dimension) must be positive");
   if (ln->a_stats) {
@@ -77,7 +79,7 @@ extern "C" int ufnd_gemm_bf16_ln(const void* A, const void* W, const float* bias
     UFND_REQUIRE(ln->a_parts >= 2 && ln->a_parts <= 24 && ln->a_parts % 2 == 0, "gemm_bf16_ln: a_parts=%d (even, 2..24)", ln->a_parts);
   }
   if (ln->r_stats) {
-    UFND_REQUIRE(residual && ln->r_gamma && ln->r_beta && ufnd_aligned(ln->r_gamma, 16) && ufnd_aligned(ln->r_beta, 16) &&
+    UFND_REQUIRE((residual || ln->residual_bf16) && ln->r_gamma && ln->r_beta && ufnd_aligned(ln->r_gamma, 16) && ufnd_aligned(ln->r_beta, 16) &&
                      ufnd_aligned(ln->r_stats, 16), "gemm_bf16_ln: r_stats needs residual, r_gamma, r_beta (16-B aligned)");
     UFND_REQUIRE(ln->r_parts >= 2 && ln->r_parts <= 24 && ln->r_parts % 2 == 0, "gemm_bf16_ln: r_parts=%d (even, 2..24)", ln->r_parts);
   }
@@ -91,6 +93,8 @@ extern "C" int ufnd_gemm_bf16_ln(const void* A, const void* W, const float* bias
   a.a_stats = ln->a_stats; a.colsum = ln->colsum; a.r_stats = ln->r_stats; a.r_gamma = ln->r_gamma; a.r_beta = ln->r_beta;
   a.out_stats = ln->out_stats; a.a_parts = ln->a_parts; a.r_parts = ln->r_parts; a.a_eps = ln->a_eps; a.r_eps = ln->r_eps;
   a.inv_h = 1.0f / (float)ln->width;
+  a.residual_b = (const __bf16*)ln->residual_bf16;
+  a.ldrb = ln->ldrb;
   int rc = launch_cfg(cfg, 4, a, (hipStream_t)stream_);
   if (rc != UFND_OK) return rc;
   UFND_CHECK_LAUNCH();

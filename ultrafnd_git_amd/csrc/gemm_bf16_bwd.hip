@@ -1,0 +1,197 @@
+// Backward forms of the encoder Linears (Tier-B backward; the reference keeps its encoders frozen -- src/core_blocks/
+// text_blocks.py:52,63 -- so these serve TrainConfig.train_encoders, SURVEY.md 8b's *_bwd list, not reference parity).
+//
+//   y = x W^T + b           x (M, K_in) bf16, W (N_out, K_in), y (M, N_out)
+//   dgrad  dx = dy W        = dy (M, N_out) x Wt (K_in, N_out)^T   -> the forward's NT kernel on the TRANSPOSED weight copy
+//                             (the trainable encoder re-casts fp32 masters to bf16 W and W^T once per step anyway); epilogue
+//                             options: + fp32 residual (the other branch's gradient), x act'(pre) (GELU / quick-GELU fused)
+//   wgrad  dW = dy^T x      = dyT (N_out, M) x xT (K_in, M)^T       -> the NT kernel again, on transposed activations, with the
+//                             token dimension as K: long K loops, few output tiles, so the K range is cut into slices
+//                             (grid = tiles x slices, fp32 partial slabs) and a reduce pass adds the slabs in slice order
+//                             (deterministic: no atomics)
+//   db     = column sums of dy, produced by the same pass that transposes dy (two-stage, fixed order)
+#define UFND_GEMM_ONLY_BWD 1
+#include "gemm_bf16_kernel.hpp"
+
+namespace {
+
+// (rows, cols) -> (cols, rows_pad) through a 64 x 64 LDS tile; 16-B global accesses on both sides.  TIn = float: cast to bf16
+// on the way (weight masters -> transposed operand copies).  Optional column sums of the source (bias gradients): the block of
+// row-tile rt writes its 64 partial sums to part[rt][col]; colsum_finish adds the row-tiles in ascending order.
+template <typename TIn>
+__global__ __launch_bounds__(256) void transpose_kernel(const TIn* __restrict__ src, int rows, int cols, int lds, __bf16* __restrict__ dst,
+                                                        int ldd, int rows_pad, float* __restrict__ part) {
+  __shared__ __bf16 tile[64][72];                    // +8 columns: the transposed reads walk rows
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tr = threadIdx.x >> 3, tc = (threadIdx.x & 7) * 8;     // 32 rows x 8 chunks of 8 columns per pass
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int r = r0 + tr + 32 * p, c = c0 + tc;
+    bf16x8 v;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = (__bf16)0.0f;
+    if (r < rows && c < cols) {                        // (cols is a multiple of 8)
+      if constexpr (std::is_same<TIn, float>::value) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src + (size_t)r * lds + c), b = *reinterpret_cast<const f32x4*>(src + (size_t)r * lds + c + 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[q] = (__bf16)a[q]; v[4 + q] = (__bf16)b[q]; }
+      } else {
+        v = *reinterpret_cast<const bf16x8*>(src + (size_t)r * lds + c);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) csum[q] += (float)v[q];
+    *reinterpret_cast<bf16x8*>(&tile[tr + 32 * p][tc]) = v;
+  }
+  __syncthreads();
+  if (part) {     // column sums over the tile's 64 rows: thread (tr, tc) holds rows {tr, tr+32}; combine the 32 row-threads through LDS
+    __shared__ float cs[32][64];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) cs[tr][tc + q] = csum[q];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < 32; ++k) s += cs[k][threadIdx.x];
+      if (c0 + (int)threadIdx.x < cols) part[(size_t)blockIdx.y * cols + c0 + threadIdx.x] = s;
+    }
+  }
+  // write: dst row = source column, 8 consecutive source rows per 16-B store
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int oc = tr + 32 * p, orow = tc;             // output row c0 + oc, output columns r0 + orow .. + 7
+    if (c0 + oc < cols && r0 + orow < rows_pad) {
+      bf16x8 v;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = tile[orow + q][oc];
+      *reinterpret_cast<bf16x8*>(dst + (size_t)(c0 + oc) * ldd + r0 + orow) = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int tiles, int cols, float* __restrict__ out, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int t = 0; t < tiles; ++t) s += part[(size_t)t * cols + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int nslab, size_t slab_stride, size_t n, float* __restrict__ out,
+                                                          int accumulate) {
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 256 * 4) {
+    f32x4 s = *reinterpret_cast<const f32x4*>(slabs + i);
+    for (int k = 1; k < nslab; ++k) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(slabs + (size_t)k * slab_stride + i);
+      s += v;
+    }
+    if (accumulate) s += *reinterpret_cast<const f32x4*>(out + i);
+    *reinterpret_cast<f32x4*>(out + i) = s;
+  }
+}
+
+// A weight-gradient product has few output tiles and a long K (the tokens): the K range is cut into slices of at least eight
+// 64-token K-steps.  Tile: the largest one that still gives the chip a full round of workgroups with the slices available.
+int wgrad_cfg(int n_out, int k_in, int m_tokens) {
+  const int smax = m_tokens / 64 / 8 > 1 ? m_tokens / 64 / 8 : 1;
+  const int cand[4] = {15, 22, 16, 20};              // 256x256, 256x192, 128x128, 128x64
+  for (int i = 0; i < 4; ++i) {
+    const TileCfg& t = kTiles[cand[i]];
+    if (k_in % t.bn) continue;
+    const long long tiles = (long long)ufnd_cdiv(n_out, t.bm) * (k_in / t.bn);
+    if (tiles * smax >= 256 || i == 3) return cand[i];
+  }
+  return 20;
+}
+int wgrad_slices(int n_out, int k_in, int m_tokens, int cfg) {
+  const long long tiles = (long long)ufnd_cdiv(n_out, kTiles[cfg].bm) * (k_in / kTiles[cfg].bn);
+  const int nk = m_tokens / 64;
+  long long s = (512 + tiles - 1) / tiles;             // about two rounds of workgroups
+  if (s > nk / 8) s = nk / 8;
+  if (s < 1) s = 1;
+  const int per = (nk + (int)s - 1) / (int)s;          // every slice must own at least one K-step
+  return (nk + per - 1) / per;
+}
+
+}  // namespace
+
+extern "C" int ufnd_gemm_bf16_dgrad(const void* dY, const void* Wt, const float* residual, const void* aux, void* out_bf16, float* out_f32,
+                                    int M, int N, int K, int lda, int ldw, int ldr, int ldaux, int ldo, int ldf, int act, void* stream_) {
+  UFND_REQUIRE(dY && Wt && (out_bf16 || out_f32), "gemm_bf16_dgrad: null operand");
+  UFND_REQUIRE(M >= 1 && N >= 64 && K >= 64 && N % 64 == 0 && K % 64 == 0, "gemm_bf16_dgrad: M=%d N=%d K=%d (need N%%64==0, K%%64==0)", M, N, K);
+  UFND_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K && ufnd_aligned(dY, 16) && ufnd_aligned(Wt, 16),
+               "gemm_bf16_dgrad: operand strides must be multiples of 8 and pointers 16-B aligned");
+  UFND_REQUIRE(!residual || (ldr % 4 == 0 && ldr >= N && ufnd_aligned(residual, 16)), "gemm_bf16_dgrad: residual alignment");
+  UFND_REQUIRE(!out_f32 || (ldf % 4 == 0 && ldf >= N && ufnd_aligned(out_f32, 16)), "gemm_bf16_dgrad: out_f32 alignment");
+  UFND_REQUIRE(!out_bf16 || (ldo % 8 == 0 && ldo >= N && ufnd_aligned(out_bf16, 16)), "gemm_bf16_dgrad: out_bf16 alignment");
+  UFND_REQUIRE(act == UFND_ACT_NONE || act == UFND_ACT_GELU_BWD || act == UFND_ACT_QUICK_GELU_BWD, "gemm_bf16_dgrad: act=%d", act);
+  UFND_REQUIRE((act == UFND_ACT_NONE) == (aux == nullptr), "gemm_bf16_dgrad: aux (the pre-activations) goes with an activation backward, and only with one");
+  UFND_REQUIRE(!aux || (!residual && ldaux % 8 == 0 && ldaux >= N && ufnd_aligned(aux, 16)), "gemm_bf16_dgrad: aux alignment (and no residual beside it)");
+  GemmArgs a{(const __bf16*)dY, (const __bf16*)Wt, nullptr, residual, (__bf16*)out_bf16, out_f32, M, N, K, lda, ldw, ldr, ldo, ldf, act, 0, 0, nullptr};
+  a.aux = (const __bf16*)aux;
+  a.ldaux = ldaux;
+  a.ksplit = 1;
+  const int cfg = auto_cfg(M, N, K);
+  UFND_REQUIRE(N % kTiles[cfg].bn == 0, "gemm_bf16_dgrad: tile %d needs N %% %d == 0", cfg, kTiles[cfg].bn);
+  int rc = launch_cfg(cfg, 6, a, (hipStream_t)stream_);
+  if (rc != UFND_OK) return rc;
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}
+
+extern "C" size_t ufnd_gemm_bf16_wgrad_workspace_floats(int n_out, int k_in, int m_tokens) {
+  if (n_out < 64 || k_in < 64 || m_tokens < 64 || k_in % 64 || m_tokens % 64) return 0;
+  const int cfg = wgrad_cfg(n_out, k_in, m_tokens);
+  return (size_t)wgrad_slices(n_out, k_in, m_tokens, cfg) * (size_t)n_out * (size_t)k_in;
+}
+
+extern "C" int ufnd_gemm_bf16_wgrad(const void* dYt, const void* Xt, float* dW, int n_out, int k_in, int m_tokens, int lda, int ldb, int ldw,
+                                    float* workspace, int accumulate, void* stream_) {
+  UFND_REQUIRE(dYt && Xt && dW && workspace, "gemm_bf16_wgrad: null operand");
+  UFND_REQUIRE(n_out >= 1 && k_in >= 64 && k_in % 64 == 0 && m_tokens >= 64 && m_tokens % 64 == 0,
+               "gemm_bf16_wgrad: N_out=%d K_in=%d tokens=%d (K_in and the padded token count must be multiples of 64)", n_out, k_in, m_tokens);
+  UFND_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda >= m_tokens && ldb >= m_tokens && ufnd_aligned(dYt, 16) && ufnd_aligned(Xt, 16),
+               "gemm_bf16_wgrad: transposed operands need 16-B aligned rows of >= tokens elements");
+  UFND_REQUIRE(ldw == k_in && ufnd_aligned(dW, 16) && ufnd_aligned(workspace, 16), "gemm_bf16_wgrad: dW must be dense (ldw == K_in) and 16-B aligned");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int cfg = wgrad_cfg(n_out, k_in, m_tokens);
+  UFND_REQUIRE(k_in % kTiles[cfg].bn == 0, "gemm_bf16_wgrad: tile %d needs K_in %% %d == 0", cfg, kTiles[cfg].bn);
+  const int S = wgrad_slices(n_out, k_in, m_tokens, cfg);
+  const size_t n = (size_t)n_out * k_in;
+  GemmArgs a{(const __bf16*)dYt, (const __bf16*)Xt, nullptr, nullptr, nullptr, workspace, n_out, k_in, m_tokens, lda, ldb, 0, 0, k_in, UFND_ACT_NONE, 0, 0, nullptr};
+  a.ksplit = S;
+  a.slab_stride = n;
+  int rc = launch_cfg(cfg, 6, a, stream);
+  if (rc != UFND_OK) return rc;
+  UFND_CHECK_LAUNCH();
+  size_t want = (n / 4 + 255) / 256;
+  const int blocks = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, stream, workspace, S, n, n, dW, accumulate);
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}
+
+extern "C" size_t ufnd_transpose_colsum_workspace_floats(int rows_pad, int cols) { return (size_t)ufnd_cdiv(rows_pad, 64) * (size_t)cols; }
+
+extern "C" int ufnd_transpose_bf16(const void* src, int src_is_f32, int rows, int cols, int lds, void* dst, int ldd, int rows_pad,
+                                   float* colsum, float* colsum_ws, int colsum_accumulate, void* stream_) {
+  UFND_REQUIRE(src && dst && rows >= 1 && cols >= 8 && cols % 8 == 0, "transpose_bf16: rows=%d cols=%d (cols %% 8 == 0)", rows, cols);
+  UFND_REQUIRE(rows_pad >= rows && rows_pad % 8 == 0 && ldd >= rows_pad && ldd % 8 == 0 && lds >= cols && lds % (src_is_f32 ? 4 : 8) == 0,
+               "transpose_bf16: rows_pad=%d ldd=%d lds=%d", rows_pad, ldd, lds);
+  UFND_REQUIRE(ufnd_aligned(src, 16) && ufnd_aligned(dst, 16), "transpose_bf16: 16-B alignment");
+  UFND_REQUIRE(!colsum || (colsum_ws && !src_is_f32), "transpose_bf16: column sums need a workspace (ufnd_transpose_colsum_workspace_floats) and a bf16 source");
+  hipStream_t stream = (hipStream_t)stream_;
+  const dim3 grid(ufnd_cdiv(cols, 64), ufnd_cdiv(rows_pad, 64));
+  if (src_is_f32)
+    hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, stream, (const float*)src, rows, cols, lds, (__bf16*)dst, ldd, rows_pad, (float*)nullptr);
+  else
+    hipLaunchKernelGGL(transpose_kernel<__bf16>, grid, dim3(256), 0, stream, (const __bf16*)src, rows, cols, lds, (__bf16*)dst, ldd, rows_pad,
+                       colsum ? colsum_ws : (float*)nullptr);
+  UFND_CHECK_LAUNCH();
+  if (colsum) {
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(ufnd_cdiv(cols, 256)), dim3(256), 0, stream, colsum_ws, (int)grid.y, cols, colsum, colsum_accumulate);
+    UFND_CHECK_LAUNCH();
+  }
+  return UFND_OK;
+}

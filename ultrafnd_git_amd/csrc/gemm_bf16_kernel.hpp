@@ -57,6 +57,15 @@ struct GemmArgs {
   int att_h;                 // heads * 64 (= rows of each of the three stacked weight blocks)
   int xcd_cols;              // 1 (0): an XCD takes whole row panels; 2: the two column halves go to XCDs 0-3 / 4-7
   float att_scale_log2e;     // 1 / sqrt(64) * log2(e)
+  // bf16 residual stream (LNX kernels): the residual operand is the bf16 rounding the previous GEMM already wrote for its
+  // consumer (16 B per 8 columns instead of 32), and no fp32 copy of the stream exists.  Exclusive with `residual`.
+  const __bf16* residual_b;
+  int ldrb;
+  // backward forms (BWD kernels only; gemm_bf16_bwd.hip)
+  int ksplit;                // > 1: the K range is cut into ksplit slices, grid = tiles x ksplit, slice s writes its fp32 partial
+  size_t slab_stride;        //      products to out_f32 + s * slab_stride (a reduce pass adds the slabs: ufnd_gemm_bf16_wgrad)
+  const __bf16* aux;         // act = UFND_ACT_GELU_BWD / UFND_ACT_QUICK_GELU_BWD: out = acc * act'(aux), aux (M, ldaux) = the
+  int ldaux;                 //      pre-activations the forward kept (dgrad through an activation, fused)
 };
 
 __device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst) {
@@ -117,9 +126,10 @@ constexpr int gemm_waves_per_simd(int BM, int BN, int WM, int WN, int STA, int S
   const int smem = (ring > cbytes ? ring : cbytes) + (LNX ? BM * 8 : 0);
   return (!ATT && smem <= 80 * 1024 ? 2 : 1) * WM * WN / 4;
 }
-template <int BM, int BN, int WM, int WN, int STA, int STB, int MI, int ABL = 0, int DBG = 0, int LNX = 0, int ATT = 0>
+template <int BM, int BN, int WM, int WN, int STA, int STB, int MI, int ABL = 0, int DBG = 0, int LNX = 0, int ATT = 0, int BWD = 0>
 __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(gemm_waves_per_simd(BM, BN, WM, WN, STA, STB, MI, LNX, ATT))))
 void gemm_bf16_kernel(const GemmArgs a) {
+  static_assert(!BWD || (!LNX && !ATT && !ABL && !DBG), "backward forms are plain kernels");
   static_assert(MI == 16 || MI == 32, "MFMA shape");
   static_assert(!ATT || (BM == 128 && BN == 384 && MI == 16 && WM * WN == 8 && LNX == 1), "fused attention tile");
   using acc_t = typename std::conditional<MI == 16, f32x4, f32x16>::type;
@@ -160,10 +170,15 @@ void gemm_bf16_kernel(const GemmArgs a) {
 
   // XCD-aware bijective remap of the block id
   const int nblk = a.m_tiles * a.n_tiles;
-  int bid;
+  int bid, kslice = 0;
   {
-    const int q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int ngrid = BWD ? nblk * (a.ksplit > 1 ? a.ksplit : 1) : nblk;
+    const int q = ngrid >> 3, r = ngrid & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    if constexpr (BWD) {       // slice-major: an XCD's contiguous share of the grid is mostly one K slice (shared operand range)
+      kslice = bid / nblk;
+      bid -= kslice * nblk;
+    }
   }
   // tile (tm, tn) of this workgroup.  Default: row-major, so an XCD's contiguous share of the grid is a set of whole row
   // panels (A fetched by one XCD, every weight row by all eight: fabric reads = A + 8 W).  xcd_cols = 2 (wide shapes:
@@ -188,12 +203,19 @@ void gemm_bf16_kernel(const GemmArgs a) {
 #pragma unroll
       for (int r = 0; r < AR; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = a.K / BK;                    // K-steps
+  int nk = a.K / BK, kbase = 0;               // K-steps (of this block's K slice)
+  if constexpr (BWD) {
+    if (a.ksplit > 1) {
+      const int per = (nk + a.ksplit - 1) / a.ksplit;
+      kbase = kslice * per * BK;
+      nk = nk - kslice * per < per ? nk - kslice * per : per;
+    }
+  }
   // per-lane source rows of my pieces (fixed over the K loop): only the column offset moves
   const int prow = lane >> 3, ppos = lane & 7;
   auto issueA = [&](int t) {
     char* buf = smem + (t % STA) * ASLOT;
-    const int k0 = t * BK;
+    const int k0 = kbase + t * BK;
 #pragma unroll
     for (int ii = 0; ii < PWA; ++ii) {
       const int p = wave + NW * ii;                  // piece id: rows 8p..8p+7 of the A tile
@@ -206,7 +228,7 @@ void gemm_bf16_kernel(const GemmArgs a) {
   };
   auto issueB = [&](int t) {
     char* buf = smem + STA * ASLOT + (t % STB) * BSLOT;
-    const int k0 = t * BK;
+    const int k0 = kbase + t * BK;
 #pragma unroll
     for (int ii = 0; ii < PWB; ++ii) {
       int p = wave + NW * ii;
@@ -462,6 +484,7 @@ void gemm_bf16_kernel(const GemmArgs a) {
     }
   }
   float* cst = reinterpret_cast<float*>(smem) + wave * MI * CP;
+  float* const outf = (BWD && a.out_f32) ? a.out_f32 + (size_t)kslice * a.slab_stride : a.out_f32;
   constexpr int CPR = TN / 8;                    // 8-column chunks per row
   constexpr int CHUNKS = MI * CPR;               // chunks per MI-row patch
   constexpr int NIT = (CHUNKS + 63) / 64;        // row-phase iterations per patch
@@ -497,6 +520,36 @@ void gemm_bf16_kernel(const GemmArgs a) {
             int row = m0 + wm * TM + i * MI + id / CPR;
             row = row < a.M ? row : a.M - 1;
             ld8(a.residual + (size_t)row * a.ldr + n0 + wn * TN + (id % CPR) * 8, rr8[it]);
+          }
+        }
+      }
+      if constexpr (BWD) {      // pre-activations of the fused activation backward: requested like a residual, used as a factor
+        if (a.aux) {
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) {
+            const int id = lane + 64 * it;
+            if (id < CHUNKS) {
+              int row = m0 + wm * TM + i * MI + id / CPR;
+              row = row < a.M ? row : a.M - 1;
+              const bf16x8 xb = *reinterpret_cast<const bf16x8*>(a.aux + (size_t)row * a.ldaux + n0 + wn * TN + (id % CPR) * 8);
+#pragma unroll
+              for (int q = 0; q < 8; ++q) rr8[it][q] = (float)xb[q];
+            }
+          }
+        }
+      }
+      if constexpr (LNX) {
+        if (a.residual_b) {
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) {
+            const int id = lane + 64 * it;
+            if (id < CHUNKS) {
+              int row = m0 + wm * TM + i * MI + id / CPR;
+              row = row < a.M ? row : a.M - 1;
+              const bf16x8 rb = *reinterpret_cast<const bf16x8*>(a.residual_b + (size_t)row * a.ldrb + n0 + wn * TN + (id % CPR) * 8);
+#pragma unroll
+              for (int q = 0; q < 8; ++q) rr8[it][q] = (float)rb[q];
+            }
           }
         }
       }
@@ -540,7 +593,18 @@ void gemm_bf16_kernel(const GemmArgs a) {
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(cst + rr * CP + cl);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(cst + rr * CP + cl + 4);
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        if (a.residual) {
+        if constexpr (BWD) {
+          if (a.aux) {
+            if (a.act == UFND_ACT_GELU_BWD) {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) v[q] = v[q] * gelu_grad_f(rr8[it][q]);
+            } else {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) v[q] = v[q] * quick_gelu_grad_f(rr8[it][q]);
+            }
+          }
+        }
+        if ((a.residual && !(BWD && a.aux)) || (LNX && a.residual_b)) {
           if constexpr (RLN) {      // the residual stream is LayerNorm(residual) * gamma + beta, never materialised
             const f32x2 ms = st_lds[wm * TM + i * MI + rr];
             if constexpr (!FIXCOL) {
@@ -580,7 +644,7 @@ void gemm_bf16_kernel(const GemmArgs a) {
         }
         if (!live) continue;
         if (a.out_f32) {
-          float* op = a.out_f32 + (size_t)row * a.ldf + col;
+          float* op = outf + (size_t)row * a.ldf + col;
           *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
           *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
         }
@@ -812,7 +876,26 @@ static int launch_cfg(int cfg, int mode, GemmArgs& a, hipStream_t stream) {
   a.m_tiles = ufnd_cdiv(a.M, t.bm);
   a.n_tiles = a.N / t.bn;
   a.xcd_cols = xcd_cols_for(a.M, a.N, a.K, a.m_tiles, a.n_tiles);
-  const dim3 grid(a.m_tiles * a.n_tiles), block(t.threads);
+  const dim3 grid(a.m_tiles * a.n_tiles * (mode == 6 && a.ksplit > 1 ? a.ksplit : 1)), block(t.threads);
+#ifdef UFND_GEMM_ONLY_BWD
+  // gemm_bf16_bwd.hip: only the backward kernels (mode 6) of the tiles the automatic choice can return
+#define X(id, BM_, BN_, WM_, WN_, SA_, SB_, MI_, LN_, PROD_)                                                                      \
+  case id:                                                                                                                        \
+    if constexpr (id == 15 || id == 16 || id == 17 || id == 20 || id == 22) {                                                     \
+      hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, SA_, SB_, MI_, 0, 0, 0, 0, 1>), grid, block, 0, stream, a);        \
+    } else {                                                                                                                      \
+      ufnd_set_error("gemm_bf16 backward: tile %d has no backward kernel", id);                                                   \
+      return UFND_ERR_INVALID;                                                                                                    \
+    }                                                                                                                             \
+    break;
+  (void)mode;
+  switch (cfg) {
+    UFND_GEMM_TILES(X)
+    default: ufnd_set_error("gemm_bf16: unknown tile config %d", cfg); return UFND_ERR_INVALID;
+  }
+#undef X
+  return UFND_OK;
+#else
 #ifdef UFND_DIAG
 #define UFND_DIAG_LAUNCH(BM_, BN_, WM_, WN_, SA_, SB_, MI_)                                                                             \
   else if (mode == 5) hipLaunchKernelGGL((gemm_bf16_kernel<BM_, BN_, WM_, WN_, SA_, SB_, MI_, 0, 1, 1>), grid, block, 0, stream, a);   \
@@ -847,6 +930,7 @@ static int launch_cfg(int cfg, int mode, GemmArgs& a, hipStream_t stream) {
 #undef X
 #undef UFND_DIAG_LAUNCH
   return UFND_OK;
+#endif
 }
 
 // Per-shape choice from the on-device sweep (tools/gemm_sweep.py, profiles/r01_gemm_sweep.txt):

@@ -22,6 +22,16 @@ The GEMM that produces a residual-stream row also writes its bf16 rounding and p
 row by W * gamma and applies  rstd (acc - mean colsum) + (b + W beta)  in its epilogue
 (`ufnd_gemm_bf16_ln`); BERT's post-LN residual LayerNorm(row) * gamma + beta is evaluated on the fly
 in the epilogue of the GEMM that adds it.  `fold_ln=False` keeps one LayerNorm kernel per LayerNorm.
+
+Residual stream dtype (`residual_dtype`, folded encoders only).  "fp32": the stream is kept in fp32 next to the bf16
+rounding the consumers read -- a residual GEMM moves 4 B in and 4 + 2 B out per element.  "bf16" (default): the rounding IS the stream
+-- the residual operand is the bf16 copy the previous GEMM wrote for its consumer, no fp32 copy is written (except by the last
+layer, for the final LayerNorm), 2 B in and 2 B out per element: 125 -> 53 MB per out-projection launch at 16,384 rows.  The
+stream then carries 8 significant bits per layer; row statistics are still taken from the fp32 sums before rounding.
+Measured at BASELINE's sizes (tests/test_gpu_fullsize.py): BERT features 9.9e-4 max-abs against 1.1e-3 with the fp32 stream,
+hidden states 9.3e-3 against 8.7e-3 relative RMS after 12 layers; ViT (pre-LN: the stream is never re-normalised) features
+7.4e-4 against 5.8e-4, hidden 8.7e-3 against 5.4e-3; end-to-end logits 3.2e-5 against 2.7e-5 (bound 1e-3) -- for
+out-projection launches 49 -> 31 us and FFN2 100 -> 83 us at 16,384 rows, the step +7 %.
 """
 from __future__ import annotations
 
@@ -112,7 +122,7 @@ class _EncoderBase(nn.Module):
                                           L.stream_ptr(A.device)), "ufnd_gemm_bf16_ex")
 
     def _gemm_ln(self, A, W, bias, out_bf16=None, out_f32=None, residual=None, act=ACT_NONE, a_stats=None, colsum=None,
-                 r_stats=None, r_gamma=None, r_beta=None, out_stats=None, eps=1e-5, which=None):
+                 r_stats=None, r_gamma=None, r_beta=None, out_stats=None, eps=1e-5, which=None, residual_bf16=None):
         """ufnd_gemm_bf16_ln: a_stats / r_stats / out_stats are (M, parts, 2) fp32 tensors."""
         M = A.shape[0]
         N, K = W.shape
@@ -125,6 +135,8 @@ class _EncoderBase(nn.Module):
         ln.a_eps = ln.r_eps = eps
         ln.width = self.hidden
         ln.tile_cfg = self.tiles.get(which, -1)
+        if residual_bf16 is not None:
+            ln.residual_bf16, ln.ldrb = residual_bf16.data_ptr(), residual_bf16.stride(0)
         import ctypes
         L.check(L.lib().ufnd_gemm_bf16_ln(A.data_ptr(), W.data_ptr(), L.ptr(bias), L.ptr(residual), L.ptr(out_bf16),
                                           L.ptr(out_f32), M, N, K, A.stride(0), W.stride(0),
@@ -200,9 +212,12 @@ class _EncoderBase(nn.Module):
 class BertTextEncoder(_EncoderBase):
     def __init__(self, layers: int = 12, hidden: int = 768, heads: int = 12, intermediate: int = 3072,
                  vocab_size: int = 30522, max_position: int = 512, type_vocab: int = 2, eps: float = 1e-12,
-                 fold_ln: bool = True):
+                 fold_ln: bool = True, residual_dtype: str = "bf16"):
         super().__init__()
         self.fold_ln = fold_ln
+        if residual_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"residual_dtype={residual_dtype!r}: 'fp32' or 'bf16'")
+        self.residual_dtype = residual_dtype
         # 128-token samples: Q/K/V projection + attention of a layer as ONE launch (ufnd_qkv_attention_bf16); bit-identical
         # to the two-launch form, which every other length uses
         self.fuse_qkv_attention = True
@@ -280,9 +295,10 @@ class BertTextEncoder(_EncoderBase):
         return self._bufs[key]
 
     @torch.no_grad()
-    def last_hidden_state(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
+    def last_hidden_state(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, n_layers: Optional[int] = None) -> torch.Tensor:
         """BertModel(input_ids, attention_mask).last_hidden_state -> (B, L, H) fp32 (a view of an
-        internal buffer, valid until the next call with the same shape)."""
+        internal buffer, valid until the next call with the same shape).  n_layers: stop after that many layers (the
+        hidden state BertModel reports as hidden_states[n_layers]; per-layer localisation in the parity tests)."""
         self._require_hip()
         dev = self.device
         B, Lq = input_ids.shape
@@ -300,6 +316,8 @@ class BertTextEncoder(_EncoderBase):
                                         b["xb"].data_ptr(), b["xf"].data_ptr(), B, Lq, H, self.vocab, self.eps,
                                         L.stream_ptr(dev)), "ufnd_bert_embed")
         fused = (B, Lq, mask) if (self.fuse_qkv_attention and Lq == 128 and self.heads % 2 == 0) else None
+        if n_layers is not None:
+            p = {"layers": p["layers"][:max(1, int(n_layers))]}
         self._layers(p, b, M, lambda qkv, ctx: self._attn(qkv, mask, ctx, B, Lq, self.heads), fused)
         return b["xf"].view(B, Lq, H)
 
@@ -344,14 +362,19 @@ class BertTextEncoder(_EncoderBase):
                 self._gemm_ln(b["y2b"], ly["wqkvf"], ly["bqkvf"], out_bf16=b["qkv"], a_stats=stp, colsum=ly["csqkv"], eps=eps, which="qkv")
             if fused is None:
                 attn(b["qkv"], b["ctx"])
+            rb = self.residual_dtype == "bf16"
+            last = i == len(p["layers"]) - 1
             if prev is None:
-                self._gemm_ln(b["ctx"], ly["wo"], ly["bo"], out_f32=y1, out_bf16=b["y1b"], residual=b["xf"], out_stats=st1, eps=eps, which="out")
+                self._gemm_ln(b["ctx"], ly["wo"], ly["bo"], out_f32=None if rb else y1, out_bf16=b["y1b"], residual=None if rb else b["xf"],
+                              residual_bf16=b["xb"] if rb else None, out_stats=st1, eps=eps, which="out")
             else:
-                self._gemm_ln(b["ctx"], ly["wo"], ly["bo"], out_f32=y1, out_bf16=b["y1b"], residual=y2, r_stats=stp,
-                              r_gamma=prev["g2"], r_beta=prev["b2n"], out_stats=st1, eps=eps, which="out")
+                self._gemm_ln(b["ctx"], ly["wo"], ly["bo"], out_f32=None if rb else y1, out_bf16=b["y1b"], residual=None if rb else y2,
+                              residual_bf16=b["y2b"] if rb else None, r_stats=stp, r_gamma=prev["g2"], r_beta=prev["b2n"], out_stats=st1,
+                              eps=eps, which="out")
             self._gemm_ln(b["y1b"], ly["w1f"], ly["bif"], out_bf16=b["h"], act=ACT_GELU, a_stats=st1, colsum=ly["cs1"], eps=eps, which="ffn1")
-            self._gemm_ln(b["h"], ly["w2"], ly["b2"], out_f32=y2, out_bf16=b["y2b"], residual=y1, r_stats=st1,
-                          r_gamma=ly["g1"], r_beta=ly["b1"], out_stats=st2, eps=eps, which="ffn2")
+            self._gemm_ln(b["h"], ly["w2"], ly["b2"], out_f32=y2 if (last or not rb) else None, out_bf16=b["y2b"], residual=None if rb else y1,
+                          residual_bf16=b["y1b"] if rb else None, r_stats=st1, r_gamma=ly["g1"], r_beta=ly["b1"], out_stats=st2, eps=eps,
+                          which="ffn2")      # (the last layer's fp32 sums feed the final, materialised LayerNorm)
             prev = ly
         self._ln(y2, H, prev["g2"], prev["b2n"], None, b["xf"], M, H, eps)           # last_hidden_state is materialised once (fp32 only: no GEMM reads it)
         self._guard_pass(st, M)
@@ -442,9 +465,12 @@ class BertTextEncoder(_EncoderBase):
 # =============================================================================================
 class ClipVisualEncoder(_EncoderBase):
     def __init__(self, layers: int = 12, hidden: int = 768, heads: int = 12, intermediate: int = 3072, patch: int = 32,
-                 image: int = 224, projection_dim: int = 512, eps: float = 1e-5, fold_ln: bool = True):
+                 image: int = 224, projection_dim: int = 512, eps: float = 1e-5, fold_ln: bool = True, residual_dtype: str = "bf16"):
         super().__init__()
         self.fold_ln = fold_ln
+        if residual_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"residual_dtype={residual_dtype!r}: 'fp32' or 'bf16'")
+        self.residual_dtype = residual_dtype
         if hidden != heads * 64:
             raise ValueError("head_dim must be 64 (hidden == heads * 64)")
         self.layers, self.hidden, self.heads, self.inter = layers, hidden, heads, intermediate
@@ -520,7 +546,17 @@ class ClipVisualEncoder(_EncoderBase):
         (CLIPVisionModelWithProjection.image_embeds)."""
         return self._run(frames[:, None])[0]
 
-    def _run(self, frames5: torch.Tensor):
+    @torch.no_grad()
+    def hidden_state(self, frames: torch.Tensor, n_layers: Optional[int] = None) -> torch.Tensor:
+        """The residual stream after `n_layers` layers (all by default), (N, 50, H) fp32: CLIPVisionModel's hidden_states[n_layers]
+        (per-layer localisation in the parity tests)."""
+        if frames.dim() == 4:
+            frames = frames[:, None]
+        _, b = self._run(frames, n_layers)
+        N = frames.shape[0] * frames.shape[1]
+        return b["xf"].view(N, self.n_patches + 1, self.hidden)
+
+    def _run(self, frames5: torch.Tensor, n_layers: Optional[int] = None):
         self._require_hip()
         dev = self.device
         B, Fr = frames5.shape[:2]
@@ -528,6 +564,8 @@ class ClipVisualEncoder(_EncoderBase):
             raise RuntimeError(f"frames: expected (B,F,3,{self.image},{self.image}), got {tuple(frames5.shape)}")
         fr = L.f32c(frames5.to(dev)).view(B * Fr, 3, self.image, self.image)
         p, b, w, V = self._pack(), self._workbufs(B, Fr), self._w, "vision_model."
+        if n_layers is not None:
+            p = dict(p, layers=p["layers"][:max(1, int(n_layers))])
         N, H, T = B * Fr, self.hidden, self.n_patches + 1
         M = N * T
         s = L.stream_ptr(dev)
@@ -546,9 +584,13 @@ class ClipVisualEncoder(_EncoderBase):
                 st1, st2 = st[2 * i], st[2 * i + 1]
                 self._gemm_ln(b["hb"], ly["wqkvf"], ly["bqkvf"], out_bf16=b["qkv"], a_stats=stA, colsum=ly["csqkv"], eps=eps, which="qkv")
                 self._attn(b["qkv"], None, b["ctx"], N, T, self.heads)
-                self._gemm_ln(b["ctx"], ly["wo"], ly["bo"], out_f32=b["xf"], out_bf16=b["hb"], residual=b["xf"], out_stats=st1, eps=eps, which="out")
+                rb = self.residual_dtype == "bf16"       # the stream is hb itself, updated in place (a tile reads exactly what it rewrites)
+                last = i == len(p["layers"]) - 1
+                self._gemm_ln(b["ctx"], ly["wo"], ly["bo"], out_f32=None if rb else b["xf"], out_bf16=b["hb"], residual=None if rb else b["xf"],
+                              residual_bf16=b["hb"] if rb else None, out_stats=st1, eps=eps, which="out")
                 self._gemm_ln(b["hb"], ly["w1f"], ly["bif"], out_bf16=b["m"], act=ACT_QUICK_GELU, a_stats=st1, colsum=ly["cs1"], eps=eps, which="ffn1")
-                self._gemm_ln(b["m"], ly["w2"], ly["b2"], out_f32=b["xf"], out_bf16=b["hb"], residual=b["xf"], out_stats=st2, eps=eps, which="ffn2")
+                self._gemm_ln(b["m"], ly["w2"], ly["b2"], out_f32=b["xf"] if (last or not rb) else None, out_bf16=b["hb"],
+                              residual=None if rb else b["xf"], residual_bf16=b["hb"] if rb else None, out_stats=st2, eps=eps, which="ffn2")
                 stA = st2
             self._ln(b["xf"], T * H, w[V + "post_layernorm.weight"], w[V + "post_layernorm.bias"], b["pooled"], None, N, H, self.eps)
             self._gemm(b["pooled"], p["wproj"], None, out_f32=b["e"])

@@ -102,6 +102,8 @@ class ForensicTrainer:
         self.device = torch.device(cfg.device)
         if self.device.type != "cuda":
             raise L.UltrafndHipError("ForensicTrainer needs a HIP device (TrainConfig.device='cuda'); no CPU path")
+        if self.device.index is None:           # "cuda" -> the current device, spelled out (tensors report cuda:N)
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.dtype = torch.float32
         self.comm = as_comm(group)
         self.group = self.comm
