@@ -498,6 +498,12 @@ int ufnd_gnn_forward(const float* x, const float* adj, int ld_adj, const ufnd_gc
 int ufnd_gnn_backward(const float* x, const ufnd_gcn_params* p, float* g_w1, float* g_b1, float* g_w2, float* g_b2, const float* d_z,
                       float* workspace, int N, int in_dim, int hid, int out_dim, float dropout_p, const ufnd_step_state* state,
                       void* stream);
+/* d loss / d text_features (B, text_dim) and d loss / d visual_features (B, visual_dim) out of the workspace a fusion backward
+ * has just filled (either pointer may be NULL).  The reference's trainer treats both as cached data
+ * (src/training/forensic_trainer.py:60-83); with trainable encoders they are where the encoders' backward starts. */
+int ufnd_fusion_feature_grads(const ufnd_dims* d, const ufnd_fusion_params* p, float* workspace, int B, float* d_text, float* d_visual,
+                              const ufnd_step_state* state, void* stream);
+
 /* d loss / d gnn_feat (B, gnn_dim) after ufnd_fusion_backward[_phase] has run on `workspace`. */
 int ufnd_fusion_gnn_input_grad(const ufnd_dims* d, const ufnd_fusion_params* p, float* workspace, int B, float* d_gnn,
                                const ufnd_step_state* state, void* stream);
@@ -561,6 +567,10 @@ size_t ufnd_layernorm_bwd_workspace_floats(int M, int H);
 int ufnd_layernorm_bwd(const float* x, int ldx, const float* gamma, const float* dy, int lddy, const float* add, int ldadd, float* dx_f32,
                        void* dx_bf16, int lddx, float* dgamma, float* dbeta, float* workspace, int accumulate, int M, int H, float eps,
                        void* stream);
+
+/* out = act(x) over n bf16 elements (act = UFND_ACT_GELU / UFND_ACT_QUICK_GELU; n a multiple of 8): the training forward keeps
+ * FFN1's pre-activations (for the fused activation backward of ufnd_gemm_bf16_dgrad) next to their activation. */
+int ufnd_act_bf16(const void* x, void* out, size_t n, int act, void* stream);
 
 /* ufnd_masked_meanpool_l2 backward: dhidden (B L, H) from dfeat (B, H) and the forward's inputs. */
 int ufnd_masked_meanpool_l2_bwd(const float* hidden, const int32_t* mask, const float* dfeat, float* dhidden, int B, int L, int H, void* stream);

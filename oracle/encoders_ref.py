@@ -238,3 +238,29 @@ def visual_features(w, frames: torch.Tensor, heads: int = 12) -> torch.Tensor:
     if Fr == 1:
         return e[:, 0]
     return field_mean_l2(e)
+
+
+# --------------------------------------------------------------------------
+# Gradients (Tier-B backward).  The reference never trains its encoders (text_blocks.py:52,63), so these are the
+# autograd gradients of the restatements above -- checked against the installed third-party classes' own autograd by
+# tests/golden/make_golden.py tier_b_grads ("parity unpinned by the reference").
+# --------------------------------------------------------------------------
+def probe_loss(features: torch.Tensor, seed: int) -> torch.Tensor:
+    """A fixed scalar functional of the features: sum(features * R), R ~ N(0, 1) seeded; d loss / d features = R."""
+    g = torch.Generator().manual_seed(seed)
+    return (features * torch.randn(features.shape, generator=g)).sum()
+
+
+def text_feature_grads(w: Dict[str, torch.Tensor], input_ids, attention_mask, seed: int, heads: int = 12):
+    """(features, {name: d probe_loss / d w[name]}) by autograd over text_features."""
+    wl = {k: v.detach().clone().requires_grad_(True) for k, v in w.items()}
+    feat = text_features(wl, input_ids, attention_mask, heads)
+    probe_loss(feat, seed).backward()
+    return feat.detach(), {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in wl.items()}
+
+
+def visual_feature_grads(w: Dict[str, torch.Tensor], frames: torch.Tensor, seed: int, heads: int = 12):
+    wl = {k: v.detach().clone().requires_grad_(True) for k, v in w.items()}
+    feat = visual_features(wl, frames, heads)
+    probe_loss(feat, seed).backward()
+    return feat.detach(), {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in wl.items()}

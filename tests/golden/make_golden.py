@@ -298,6 +298,59 @@ def tier_b():
     np.savez_compressed(HERE / "tier_b.npz", **store)
 
 
+def tier_b_grads():
+    """Gradients of the encoders (Tier-B backward).  The reference never trains them; the oracle's autograd gradients
+    (oracle.encoders_ref.*_feature_grads) are checked here against the installed third-party classes' OWN autograd on the same
+    seeded weights and probe loss, and digests of every gradient tensor are stored (tier_b_grads.npz)."""
+    from transformers import BertConfig, BertModel, CLIPVisionConfig, CLIPVisionModelWithProjection
+    from oracle import encoders_ref as E
+
+    store = {}
+    VOC, LOSS_SEED = 1000, 77
+    for tag, layers, B, L, seed in (("bert2_L64", 2, 3, 64, 24), ("bert2_L128", 2, 2, 128, 25)):
+        w = E.seeded_weights(E.bert_shapes(layers=layers, vocab=VOC), seed)
+        m = BertModel(BertConfig(num_hidden_layers=layers, vocab_size=VOC), add_pooling_layer=False).eval()      # eval: no dropout
+        m.load_state_dict(w, strict=True)
+        ids, mask = E.synthetic_tokens(seed + 100, B, L, vocab=VOC, min_len=8)
+        feat = E.masked_meanpool_l2(m(input_ids=ids, attention_mask=mask).last_hidden_state, mask)
+        E.probe_loss(feat, LOSS_SEED).backward()
+        ref = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in m.named_parameters()}
+        _, ora = E.text_feature_grads(w, ids, mask, LOSS_SEED)
+        worst = 0.0
+        for k, g in ref.items():
+            scale = max(g.abs().max().item(), 1e-3 * max(x.abs().max().item() for x in ref.values()))
+            worst = max(worst, (g - ora[k]).abs().max().item() / scale)
+            put_digest(store, f"{tag}/grad/{k}", ora[k])
+        assert worst <= 2e-4, (tag, worst)
+        store[f"{tag}/ids"], store[f"{tag}/mask"] = ids.numpy().astype(np.int64), mask.numpy().astype(np.int64)
+        store[f"{tag}/meta"] = np.array(json.dumps({"layers": layers, "vocab": VOC, "weight_seed": seed, "loss_seed": LOSS_SEED,
+                                                    "keys": list(ref.keys())}))
+        print(f"tier_b_grads {tag}: oracle-vs-third-party autograd, worst relative gradient error {worst:.2e} over {len(ref)} tensors")
+    for tag, layers, B, Fr, seed in (("vit2_F1", 2, 3, 1, 33), ("vit2_F2", 2, 2, 2, 34)):
+        w = E.seeded_weights(E.vit_shapes(layers=layers), seed)
+        m = CLIPVisionModelWithProjection(CLIPVisionConfig(num_hidden_layers=layers)).eval()
+        m.load_state_dict(w, strict=True)
+        frames = E.synthetic_frames(seed + 100, B, Fr)
+        e = m(pixel_values=frames.reshape(B * Fr, 3, 224, 224)).image_embeds
+        u = (e / (e.norm(dim=-1, keepdim=True) + 1e-9)).view(B, Fr, -1)
+        feat = u[:, 0] if Fr == 1 else E.field_mean_l2(u)
+        E.probe_loss(feat, LOSS_SEED).backward()
+        ref = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in m.named_parameters()}
+        _, ora = E.visual_feature_grads(w, frames, LOSS_SEED)
+        worst = 0.0
+        for k, g in ref.items():
+            if k not in ora:
+                continue                      # (position_ids-like buffers are not parameters of the restatement)
+            scale = max(g.abs().max().item(), 1e-3 * max(x.abs().max().item() for x in ref.values()))
+            worst = max(worst, (g - ora[k]).abs().max().item() / scale)
+            put_digest(store, f"{tag}/grad/{k}", ora[k])
+        assert worst <= 2e-4, (tag, worst)
+        store[f"{tag}/meta"] = np.array(json.dumps({"layers": layers, "weight_seed": seed, "frame_seed": seed + 100, "B": B, "F": Fr,
+                                                    "loss_seed": LOSS_SEED, "keys": [k for k in ref if k in ora]}))
+        print(f"tier_b_grads {tag}: oracle-vs-third-party autograd, worst relative gradient error {worst:.2e} over {len(ref)} tensors")
+    np.savez_compressed(HERE / "tier_b_grads.npz", **store)
+
+
 def init_parity():
     """Per-tensor checksums of the reference modules' INITIAL weights under torch.manual_seed(123): the
     mirror constructs its parameters in the same order, so the same seed must give the same weights."""
@@ -544,7 +597,7 @@ def gnn_model():
 if __name__ == "__main__":
     part = sys.argv[1] if len(sys.argv) > 1 else "all"
     if part == "all":
-        for p in ("tier_a", "metrics", "tier_b", "temporal", "temporal_seq", "init_parity", "gcn", "gnn_model"):
+        for p in ("tier_a", "metrics", "tier_b", "tier_b_grads", "temporal", "temporal_seq", "init_parity", "gcn", "gnn_model"):
             subprocess.check_call([sys.executable, str(Path(__file__).resolve()), p], cwd=str(REPO))
     else:
-        {"tier_a": tier_a, "metrics": metrics, "tier_b": tier_b, "temporal": temporal, "temporal_seq": temporal_seq, "init_parity": init_parity, "gcn": gcn, "gnn_model": gnn_model}[part]()
+        {"tier_a": tier_a, "metrics": metrics, "tier_b": tier_b, "tier_b_grads": tier_b_grads, "temporal": temporal, "temporal_seq": temporal_seq, "init_parity": init_parity, "gcn": gcn, "gnn_model": gnn_model}[part]()

@@ -70,3 +70,25 @@ def test_temporal_sequence_path_matches_reference():
         assert (o_train - torch.from_numpy(g[f"{name}/out_train"])).abs().max().item() <= 2e-5, name
         for kk, v in stats.items():
             assert (v - torch.from_numpy(g[f"{name}/after/{kk}"])).abs().max().item() <= 2e-5, (name, kk)
+
+
+def test_oracle_encoder_gradients_match_the_third_party_autograd_fixture():
+    """tier_b_grads.npz: digests of every encoder gradient for a seeded probe loss, stored after make_golden.py checked the
+    oracle's autograd against the installed third-party classes' own autograd (2e-6 .. 7e-6 relative).  The reference never
+    trains its encoders (text_blocks.py:52,63): 'parity unpinned by the reference'."""
+    import json
+    from tests.helpers import assert_digest_close, load_npz
+    from oracle import encoders_ref as E
+    z = load_npz("tier_b_grads.npz")
+    meta = json.loads(str(z["bert2_L64/meta"]))
+    w = E.seeded_weights(E.bert_shapes(layers=meta["layers"], vocab=meta["vocab"]), meta["weight_seed"])
+    ids, mask = torch.from_numpy(z["bert2_L64/ids"]), torch.from_numpy(z["bert2_L64/mask"])
+    _, g = E.text_feature_grads(w, ids, mask, meta["loss_seed"])
+    assert len(meta["keys"]) == 37
+    for k in meta["keys"]:
+        assert_digest_close(z, f"bert2_L64/grad/{k}", g[k], 1e-4, 1e-7, k)
+    meta = json.loads(str(z["vit2_F2/meta"]))
+    w = E.seeded_weights(E.vit_shapes(layers=meta["layers"]), meta["weight_seed"])
+    _, g = E.visual_feature_grads(w, E.synthetic_frames(meta["frame_seed"], meta["B"], meta["F"]), meta["loss_seed"])
+    for k in meta["keys"]:
+        assert_digest_close(z, f"vit2_F2/grad/{k}", g[k], 1e-4, 1e-7, k)

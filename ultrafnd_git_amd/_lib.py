@@ -156,6 +156,7 @@ def _declare_encoders(lib: C.CDLL) -> None:
         "ufnd_l2norm_frames_bwd": [P, P, P, I, I, I, P],
         "ufnd_bert_embed_bwd": [P, P, P, P, P, I, I, I, I, I, I, P],
         "ufnd_vit_assemble_bwd": [P, P, P, P, I, I, I, P],
+        "ufnd_act_bf16": [P, P, S, I, P],
     })
     for name, argtypes in sigs.items():
         fn = getattr(lib, name)
@@ -187,6 +188,8 @@ def _declare_encoders(lib: C.CDLL) -> None:
     lib.ufnd_gnn_backward.restype = I
     lib.ufnd_fusion_gnn_input_grad.argtypes = [C.POINTER(Dims), C.POINTER(FusionParams), P, I, P, P, P]
     lib.ufnd_fusion_gnn_input_grad.restype = I
+    lib.ufnd_fusion_feature_grads.argtypes = [C.POINTER(Dims), C.POINTER(FusionParams), P, I, P, P, P, P]
+    lib.ufnd_fusion_feature_grads.restype = I
     lib.ufnd_gather_rows.argtypes = [P, I, C.POINTER(GatherItem), I, P]
     lib.ufnd_gather_rows.restype = I
     lib.ufnd_tcn_weight_ld.argtypes = [I, I]

@@ -118,9 +118,10 @@ class ArenaModule(nn.Module):
         return self._arena.grad_view(self.akey(name))
 
 
-def rehome(modules: Sequence[ArenaModule], prefixes: Sequence[str]) -> FlatArena:
+def rehome(modules: Sequence[ArenaModule], prefixes: Sequence[str], extra_grad_groups: Sequence[Group] = ()) -> FlatArena:
     """Move the parameters of `modules` into one new FlatArena (values preserved) and re-point
-    every nn.Parameter at its view.  Grad region order = modules in the given order."""
+    every nn.Parameter at its view.  Grad region order = modules in the given order, then `extra_grad_groups` (already
+    prefixed keys of tensors that are not nn.Parameters: the trainable encoders' masters, bound by their owners)."""
     device = next(modules[0].parameters()).device
     grad_groups: List[Group] = []
     nograd_groups: List[Group] = []
@@ -128,6 +129,7 @@ def rehome(modules: Sequence[ArenaModule], prefixes: Sequence[str]) -> FlatArena
         gg, ng = m._arena_groups()
         grad_groups += [[(pre + k, s) for k, s in g] for g in gg]
         nograd_groups += [[(pre + k, s) for k, s in g] for g in ng]
+    grad_groups += [list(g) for g in extra_grad_groups]
     arena = FlatArena(grad_groups, nograd_groups, device)
     for m, pre in zip(modules, prefixes):
         named = dict(m.named_parameters())

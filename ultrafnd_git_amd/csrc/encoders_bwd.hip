@@ -278,6 +278,18 @@ __global__ __launch_bounds__(256) void patch_rows_kernel(const float* __restrict
   }
 }
 
+// out = act(x), bf16 -> bf16, 8 elements per thread (training forward: FFN1 keeps its pre-activations AND their activation; the
+// same erf-GELU / quick-GELU as the GEMM epilogues)
+__global__ __launch_bounds__(256) void act_bf16_kernel(const __bf16* __restrict__ x, __bf16* __restrict__ out, size_t n8, int act) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + i * 8);
+    bf16x8 o;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) o[q] = (__bf16)(act == UFND_ACT_GELU ? gelu_fast_f((float)v[q]) : quick_gelu_fast_f((float)v[q]));
+    *reinterpret_cast<bf16x8*>(out + i * 8) = o;
+  }
+}
+
 #define NI_LAUNCH(H, KERNEL, GRID, STREAM, ...)                                                       \
   do {                                                                                                \
     if ((H) == 256) hipLaunchKernelGGL((KERNEL<1>), GRID, dim3(256), 0, STREAM, __VA_ARGS__);         \
@@ -290,6 +302,15 @@ inline bool h_ok(int H) { return H == 256 || H == 512 || H == 768 || H == 1024; 
 inline int ln_bwd_blocks(int M) { const int b = ufnd_cdiv(M, 8); return b < 1 ? 1 : (b > 512 ? 512 : b); }
 
 }  // namespace
+
+extern "C" int ufnd_act_bf16(const void* x, void* out, size_t n, int act, void* stream_) {
+  UFND_REQUIRE(x && out && n >= 8 && n % 8 == 0 && ufnd_aligned(x, 16) && ufnd_aligned(out, 16), "act_bf16: n=%zu (multiple of 8), 16-B alignment", n);
+  UFND_REQUIRE(act == UFND_ACT_GELU || act == UFND_ACT_QUICK_GELU, "act_bf16: act=%d", act);
+  size_t want = (n / 8 + 255) / 256;
+  hipLaunchKernelGGL(act_bf16_kernel, dim3((unsigned)(want > 4096 ? 4096 : want)), dim3(256), 0, (hipStream_t)stream_, (const __bf16*)x, (__bf16*)out, n / 8, act);
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}
 
 extern "C" size_t ufnd_layernorm_bwd_workspace_floats(int M, int H) { return (size_t)ln_bwd_blocks(M) * 2 * (size_t)H; }
 

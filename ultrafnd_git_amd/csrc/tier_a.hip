@@ -957,6 +957,24 @@ extern "C" int ufnd_fusion_gnn_input_grad(const ufnd_dims* d, const ufnd_fusion_
   return launch_nn(&n, 1, state, (hipStream_t)stream_);
 }
 
+// d loss / d text_features = dt . text_proj.weight and d loss / d visual_features = dv . visual_proj.weight, from the workspace a
+// fusion backward has just filled.  In the reference trainer these inputs are cached data (forensic_trainer.py:60-83); with
+// trainable encoders (TrainConfig.train_encoders) they are the encoders' outputs and this is where their backward starts.
+extern "C" int ufnd_fusion_feature_grads(const ufnd_dims* d, const ufnd_fusion_params* p, float* workspace, int B, float* d_text,
+                                         float* d_visual, const ufnd_step_state* state, void* stream_) {
+  TRY(check_dims(d, B));
+  UFND_REQUIRE(p && workspace && (d_text || d_visual), "fusion_feature_grads: null argument");
+  UFND_REQUIRE((!d_text || ufnd_aligned(d_text, 16)) && (!d_visual || ufnd_aligned(d_visual, 16)), "fusion_feature_grads: alignment");
+  FusionWs w = carve_fusion(*d, B, workspace);
+  const int H = d->hidden;
+  NnProb n[2];
+  int k = 0;
+  if (d_text) n[k++] = NnProb{w.dtavu, p->text_w, d_text, nullptr, nullptr, B, H, d->text_dim, H, d->text_dim, d->text_dim, 0, 0, 0.0f, 0, 0, 1};
+  if (d_visual)
+    n[k++] = NnProb{w.dtavu + (size_t)2 * B * H, p->visual_w, d_visual, nullptr, nullptr, B, H, d->visual_dim, H, d->visual_dim, d->visual_dim, 0, 0, 0.0f, 0, 0, 1};
+  return launch_nn(n, k, state, (hipStream_t)stream_);
+}
+
 extern "C" int ufnd_classifier_forward(const ufnd_dims* d, const ufnd_clf_params* p, const float* fused, int ld_fused,
                                        const float* aux, int B, int train, float* workspace, float* logits,
                                        float* probs, const ufnd_step_state* state, void* stream_) {

@@ -149,14 +149,22 @@ class HeadStep:
                                                b["dfused"].data_ptr(), self.fusion.hidden, None, st, s, side, 1,
                                                (L.BWD_ALL, L.BWD_FUSE_MLP, L.BWD_REST)[part]), "ufnd_fusion_backward_phase")
 
-    def fwd_bwd(self, b: dict, B: int, post: Optional[Callable[[], None]] = None) -> None:
+    def feature_grads(self, b: dict, B: int, d_text: Optional[torch.Tensor], d_visual: Optional[torch.Tensor]) -> None:
+        """d loss / d text_features, d loss / d visual_features out of the workspace the fusion backward has filled (where the
+        trainable encoders' backward starts; the reference's trainer treats both as cached data, forensic_trainer.py:60-83)."""
+        L.check(L.lib().ufnd_fusion_feature_grads(C.byref(b["dims"]), C.byref(self.fusion.param_table()), b["fws"].data_ptr(), B, L.ptr(d_text),
+                                                  L.ptr(d_visual), self.optim.state.ptr, L.stream_ptr(self.device)), "ufnd_fusion_feature_grads")
+
+    def fwd_bwd(self, b: dict, B: int, post: Optional[Callable[[], None]] = None, tail: Optional[Callable[[], None]] = None) -> None:
         """fusion fwd -> clf fwd -> CE -> clf bwd -> fusion bwd, eager or replayed from a hipGraph.  With a gradient
         exchange (data parallel) the backward is cut after the fuse_mlp phase: bucket 0 of the exchange starts there and
         runs beside the rest of backward, bucket 1 follows it (dp.py); the caller's reducer.finish() joins both.
-        `post()` (optional) is enqueued eagerly behind the backward and in front of the last bucket (the integrated
-        variant's GNN backward, the trainable encoders' feature gradients): its gradients close the arena."""
+        `post()` (optional) is enqueued eagerly behind the backward and in front of the head's last bucket (the integrated
+        variant's GNN backward: its gradients close that bucket); `tail()` behind that bucket's start (the trainable encoders'
+        backward, which starts its own buckets)."""
         dp = self.reducer.active
         post = post or (lambda: None)
+        tail = tail or (lambda: None)
 
         def first():
             self.enqueue_forward(b, B, True, True)
@@ -173,6 +181,7 @@ class HeadStep:
                 self.reducer.start(1)
             else:
                 post()
+            tail()
             return
         key = "graph_dp" if dp else "graph"
         if b.get(key) is None:
@@ -198,3 +207,4 @@ class HeadStep:
             self.reducer.start(1)
         else:
             post()
+        tail()

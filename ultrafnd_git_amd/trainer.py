@@ -90,6 +90,9 @@ class TrainConfig:
     # gradient exchange variants (dp.py): payload "fp32" | "bf16", algorithm "all_reduce" | "rs_ag"
     grad_payload: str = "fp32"
     grad_exchange: str = "all_reduce"
+    # fine-tune the encoders with the head (encoder_train.py: forward with saved activations + hand-written backward; needs
+    # encode_inline and both encoders).  The reference keeps them frozen (text_blocks.py:52,63): False reproduces it.
+    train_encoders: bool = False
 
 
 class ForensicTrainer:
@@ -150,6 +153,16 @@ class ForensicTrainer:
 
         self.fusion = CrossModalTransformer(config_path="configs/model_configs/fusion.yaml").to(self.device)
         self.clf = DeepTruthClassifier(config_path="configs/model_configs/classifier.yaml").to(self.device)
+        # trainable encoders: their masters join the arena behind the head's, in gradient-ready order (text, then visual)
+        self.text_bp = self.vis_bp = None
+        extra = []
+        if cfg.train_encoders:
+            if not cfg.encode_inline or text_encoder is None or visual_encoder is None or cfg.gnn_in_graph:
+                raise ValueError("train_encoders=True needs encode_inline=True with text_encoder= and visual_encoder= (and not gnn_in_graph)")
+            from .encoder_train import TextBackprop, VisualBackprop
+            text_encoder._require_hip(); visual_encoder._require_hip()
+            self.text_bp, self.vis_bp = TextBackprop(text_encoder), VisualBackprop(visual_encoder)
+            extra = [[("text." + k, s) for k, s in g] for g in self.text_bp.groups()] + [[("vis." + k, s) for k, s in g] for g in self.vis_bp.groups()]
         # one flat arena for both modules: clf first (its gradients are ready first in backward)
         if cfg.gnn_in_graph:
             from .gnn_model import GNNModel
@@ -157,9 +170,16 @@ class ForensicTrainer:
             self.arena = rehome([self.clf, self.fusion, self.gnn_model], ["clf.", "fusion.", "gnn."])        # its gradients are ready last
             self._epoch = 0
         else:
-            self.arena = rehome([self.clf, self.fusion], ["clf.", "fusion."])
-        # two buckets in gradient-ready order: [classifier | fuse_mlp] is complete after the first phase of backward
-        self.reducer = GradReducer(self.arena.ensure_grad(), group=self.comm, bounds=[self.arena.offsets["fusion.attn_tv.q.weight"][0]],
+            self.arena = rehome([self.clf, self.fusion], ["clf.", "fusion."], extra_grad_groups=extra)
+        # buckets in gradient-ready order: [classifier | fuse_mlp] is complete after the first phase of backward, the rest of the
+        # head after the second; with trainable encoders, the text encoder's and the visual encoder's gradients follow
+        bounds = [self.arena.offsets["fusion.attn_tv.q.weight"][0]]
+        if self.text_bp is not None:
+            self.text_bp.bind(self.arena, "text.")
+            self.vis_bp.bind(self.arena, "vis.")
+            bounds += [self.arena.offsets[extra[0][0][0]][0], self.arena.offsets["vis." + self.vis_bp.groups()[0][0][0]][0]]
+            self._enc_dirty = False
+        self.reducer = GradReducer(self.arena.ensure_grad(), group=self.comm, bounds=bounds,
                                    force=force_exchange, payload=cfg.grad_payload, algorithm=cfg.grad_exchange)
         self.optim = FusedAdamW(self.arena, lr=cfg.lr, weight_decay=cfg.weight_decay,
                                 max_norm=cfg.grad_clip if cfg.grad_clip and cfg.grad_clip > 0 else 0.0,
@@ -209,6 +229,11 @@ class ForensicTrainer:
             return
         inline = self.cfg.encode_inline and "input_ids" in batch
         if inline:
+            if self.text_bp is not None and self._enc_dirty:      # the masters moved since the frozen path last packed its operands
+                for enc in (self.text_encoder, self.visual_encoder):
+                    enc._packed = None
+                    enc.weights_version += 1
+                self._enc_dirty = False
             self.pipe.prefetch_features(batch, 0)
             for ev in self.pipe.feat_ready[0]:
                 torch.cuda.current_stream(self.device).wait_event(ev)
@@ -266,9 +291,53 @@ class ForensicTrainer:
                 "ufnd_fusion_gnn_input_grad")
         self.gnn_model.backward(b["dgnn"])
 
+    def _train_step_encoders(self, batch: Dict[str, torch.Tensor]) -> dict:
+        """train_step with trainable encoders: encoder forwards that keep their activations -> head forward / loss / backward
+        -> feature gradients -> encoder backwards (text, then visual; each closes its bucket of the exchange) -> one global-norm
+        clip + AdamW over the joint arena -> the encoders' bf16 operands re-cast from the updated masters.  One stream, no
+        lookahead: every step changes the encoders' weights."""
+        B = _batch_size(batch)
+        b = self.head.bufs(B, True)
+        if "dtext" not in b:
+            b["dtext"] = torch.empty(B, 768, dtype=torch.float32, device=self.device)
+            b["dvis"] = torch.empty(B, 512, dtype=torch.float32, device=self.device)
+        b["text"].copy_(self.text_bp.forward_train(batch["input_ids"], batch["attention_mask"]))
+        b["visual"].copy_(self.vis_bp.forward_train(batch["frames"]))
+        b["audio"].copy_(batch["audio_features"])
+        if self.temporal_net is not None:       # (temporal = align(text, visual) is data, as in the reference's cache: no gradient through it)
+            self.temporal_net.align_batch(b["text"], b["visual"], out=b["temporal"])
+        else:
+            b["temporal"].copy_(batch["temporal_features"])
+        b["aux"].copy_(batch["aux"])
+        b["label"].copy_(batch["label"])
+        if "gnn_feat" in batch and batch["gnn_feat"] is not None:
+            b["gnn"].copy_(batch["gnn_feat"])
+        else:
+            idx = batch["index"]
+            torch.index_select(self._dataset("train").G, 0, idx.to(self.device), out=b["gnn"])
+
+        def tail():
+            self.head.feature_grads(b, B, b["dtext"], b["dvis"])
+            self.text_bp.backward(b["dtext"])
+            if self.reducer.active:
+                self.reducer.start(2)
+            self.vis_bp.backward(b["dvis"])
+            if self.reducer.active:
+                self.reducer.start(3)
+        self.head.fwd_bwd(b, B, tail=tail)
+        self.reducer.finish()
+        self.optim.clip_and_step()
+        self.text_bp.refresh_operands()
+        self.vis_bp.refresh_operands()
+        self._enc_dirty = True
+        return {"loss": self.optim.state.float_view("loss"), "probs": b["probs"], "y": b["label"],
+                "forensic": b["forensic"], "logits": b["logits"]}
+
     def train_step(self, batch: Dict[str, torch.Tensor], split: str = "train") -> dict:
         """One iteration of the reference's train loop body (forensic_trainer.py:285-298):
         forward, CE, backward, [all-reduce], clip_grad_norm_, AdamW.step.  Returns device tensors."""
+        if self.text_bp is not None and "input_ids" in batch:
+            return self._train_step_encoders(batch)
         B = _batch_size(batch)
         b = self.head.bufs(B, True)
         self._load_batch(b, batch, split)
@@ -317,7 +386,7 @@ class ForensicTrainer:
         ys: List[torch.Tensor] = []
         p1s: List[torch.Tensor] = []
         fors: List[torch.Tensor] = []
-        lookahead = (is_train and self.cfg.encode_inline and int(self.cfg.encoder_lookahead) > 1 and self.cfg.use_graph and
+        lookahead = (is_train and self.cfg.encode_inline and int(self.cfg.encoder_lookahead) > 1 and self.cfg.use_graph and self.text_bp is None and
                      self.gnn_model is None and isinstance(loader, DeviceBatchLoader) and loader.dataset.ids_tok is not None and
                      loader.dataset.frames is not None and loader.dataset.G is not None)
         if lookahead:
