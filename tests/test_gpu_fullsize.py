@@ -110,14 +110,19 @@ def test_outlier_shaped_weights_full_depth_pass_folded_or_trip_the_guard(off):
         warnings.simplefilter("always")
         strict = enc(ids, mask, strict=True).clone().cpu()
     es = feature_errors(strict, ref)
-    print(f"outlier-shaped weights, offset {off}: guard ratio {ratio:.2f}; folded {e}; strict {es}; folding {'kept' if enc.fold_ln else 'switched off'}")
-    # the features are unit vectors dominated by the four hot dimensions, so max-abs is taken relative to the largest entry;
-    # bounds = 2 x the ordinary 12-layer values (rel-L2 8.3e-3, 1 - cos 3.5e-5 measured with off = 1)
-    top = ref.abs().max().item()
-    ok = lambda x: x["rel_l2"] <= 1.7e-2 and x["one_minus_cos"] <= 7e-5 and x["max_abs"] <= 1.5e-2 * top
-    assert ok(es), es                                                          # what a strict caller gets
+    mat = BertTextEncoder(layers=12, vocab_size=1000, fold_ln=False)           # the same weights with one LayerNorm kernel per LayerNorm
+    mat.load_state_dict(w)
+    em = feature_errors(mat.to(DEV)(ids, mask).clone().cpu(), ref)
+    print(f"outlier-shaped weights, offset {off}: guard ratio {ratio:.2f}; folded {e}; strict {es}; materialised {em}; "
+          f"folding {'kept' if enc.fold_ln else 'switched off'}")
+    # 20x gains on four dimensions amplify every bf16 rounding upstream of them: the MATERIALISED encoder's own error on these
+    # weights is the yardstick (measured with off = 1: rel-L2 1.3e-2, 1 - cos 8e-5, against 8.3e-3 / 3.5e-5 on ordinary weights);
+    # per-column outliers cost the folded and the materialised path the same, only a per-row offset separates them
+    near = lambda x: x["rel_l2"] <= 1.5 * em["rel_l2"] + 1e-3 and x["one_minus_cos"] <= 2.0 * em["one_minus_cos"] + 1e-5
+    assert em["rel_l2"] <= 3e-2 and em["one_minus_cos"] <= 2e-4, em
+    assert near(es), (es, em)                                                  # what a strict caller gets
     if off <= 1.0:
-        assert ratio <= enc.FOLD_GUARD_MAX and enc.fold_ln and ok(e), (ratio, e)
+        assert ratio <= enc.FOLD_GUARD_MAX and enc.fold_ln and near(e), (ratio, e, em)
     else:
         assert ratio > enc.FOLD_GUARD_MAX and not enc.fold_ln, ratio           # tripped: the strict pass repeated the batch unfolded
 

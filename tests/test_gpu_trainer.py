@@ -232,6 +232,13 @@ def test_fit_with_encoders_inside_the_step_and_the_fold_guard_of_every_pass(tmp_
     best = tr.fit()
     res = tr.test()
     assert 0.0 <= best <= 1.0 and np.isfinite(res["test_loss"])
+    # forward-only batches (validation / test) see the encoders' features too (they are written to the train step's input slot)
+    vb = next(iter(tr.val_loader))
+    tr._forward_batch(vb, "val")
+    torch.cuda.synchronize()
+    nb = len(dict.__getitem__(vb, "index"))
+    assert torch.equal(tr.head.bufs(nb, False)["text"], tenc(vb["input_ids"], vb["attention_mask"]))
+    assert torch.equal(tr.head.bufs(nb, False)["visual"], venc(vb["frames"]))
     assert tenc.fold_ln and venc.fold_ln and 0.0 < tenc.fold_ratio() < tenc.FOLD_GUARD_MAX       # the guard ran in every pass and did not trip
     assert tr.pipe.stats["fold_trips"] == 0 and tr.pipe.stats["pinned_replays"] > 0 and tr.pipe.stats["staged_replays"] > 0
     # a tripped guard switches the encoder to materialised LayerNorms and drops its captured graphs; new weights drop them too

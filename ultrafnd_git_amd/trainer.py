@@ -238,6 +238,10 @@ class ForensicTrainer:
             for ev in self.pipe.feat_ready[0]:
                 torch.cuda.current_stream(self.device).wait_event(ev)
             self.pipe.feat_ready[0] = None
+            slot0 = self.head.bufs(_batch_size(batch), True, 0)       # the encoders write input slot 0 of the TRAIN buffers
+            if slot0 is not b:                                        # (forward-only batches have buffers of their own)
+                b["text"].copy_(slot0["text"])
+                b["visual"].copy_(slot0["visual"])
         else:
             b["text"].copy_(batch["text_features"])
             b["visual"].copy_(batch["visual_features"])
