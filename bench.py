@@ -173,6 +173,66 @@ def exchange_probe(tr, dev, n: int = 20):
             "what": f"median of {n} two-bucket sum-all-reduces of the fp32 gradient arena, alone on the GPU, max over ranks"}
 
 
+def bench_train_encoders(args, dev, world, rank):
+    """The same step with BOTH encoders trained (TrainConfig.train_encoders): encoder forwards that keep their activations,
+    head forward / CE / backward, feature gradients, encoder backwards (data and weight gradients of every Linear, attention,
+    LayerNorms, embeddings), one global-norm clip + AdamW over head + encoders (197 M parameters), operand re-cast.  Not
+    the headline (the reference never trains its encoders); roofline = 3 x the forward's GEMM FLOPs / step time."""
+    from ultrafnd_git_amd.encoders import BertTextEncoder, ClipVisualEncoder
+    from ultrafnd_git_amd.temporal import TemporalSyncNet
+    from ultrafnd_git_amd.trainer import ForensicTrainer, TrainConfig, synthetic_cache
+    B = args.batch
+    torch.manual_seed(42)
+    tenc, venc = BertTextEncoder().to(dev), ClipVisualEncoder().to(dev)
+    cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir="/tmp/ufnd_bench", batch_size=B, device=str(dev), use_graph=not args.no_graph,
+                      encode_inline=True, seed=42, train_encoders=True)
+    tsync = TemporalSyncNet(in_dim=768, out_dim=256).to(dev)
+    tr = ForensicTrainer(cfg, cache=synthetic_cache(64, seed=1), text_encoder=tenc, visual_encoder=venc, temporal_net=tsync)
+    tr.fusion.train(); tr.clf.train()
+    batches = make_batches(B, 4, 42 + 2 + 1000 * rank, dev)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if dist.is_initialized():
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+    for i in range(args.warmup):
+        tr.train_step(batches[i % 4])
+    blocks = []
+    for _ in range(max(1, args.repeats)):
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            tr.train_step(batches[i % 4])
+        fence()
+        dt = time.perf_counter() - t0
+        if dist.is_initialized():
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        blocks.append(dt)
+    dt = sorted(blocks)[len(blocks) // 2]
+    flops, _ = gemm_flops_per_step(B)
+    step_ms = dt / args.steps * 1e3
+    ach = 3.0 * flops / (step_ms * 1e-3) / 1e12
+    xch = exchange_probe(tr, dev) if dist.is_initialized() else {"ranks_seen": 1}
+    if rank == 0:
+        print(json.dumps({"metric": "train-step samples/sec with BOTH encoders trained (not the headline: the reference keeps them frozen)",
+                          "value": round(world * B * args.steps / dt, 2), "unit": "samples/s", "n_gpus": world, "ranks_seen": xch["ranks_seen"],
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 4), "higher_is_better": True, "scaling": "weak",
+                          "dtype": "bf16", "data": "synthetic", "final_loss": float(tr.optim.state.read().loss),
+                          "config": {"workload": f"full Ultrafnd step with trainable encoders (BERT-base L={SEQ_LEN} + {FRAMES} x ViT-B/32 fwd AND bwd, "
+                                                 "fusion + classifier fwd / bwd, one clip + AdamW over head + encoders)", "per_gpu_batch": B,
+                                     "trainable_parameters": int(tr.arena.n_grad), "parallelism": f"dp{world}"},
+                          "timing": {"ms_per_step_blocks": [round(x / args.steps * 1e3, 4) for x in blocks]}, "exchange": xch,
+                          "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (forward, data-gradient and weight-gradient forms)",
+                                       "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                                       "basis": "3 x the forward's algorithmic GEMM FLOPs (forward + dgrad + wgrad of every encoder Linear) / step time",
+                                       "flops_per_step": 3.0 * flops, "traffic": None}}))
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def launch_command(n: int, argv: list, port: int) -> list:
     """The torchrun command line `python bench.py --gpus n ...` turns itself into (one rank per GPU, RCCL over xGMI)."""
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
@@ -226,6 +286,9 @@ def main():
                     help="encoders' residual stream: fp32 beside the bf16 operands, or the bf16 rounding itself (encoders.py)")
     ap.add_argument("--head-only", action="store_true",
                     help="secondary measurement: the reference's actual training mode (cached features, no encoders in the step)")
+    ap.add_argument("--train-encoders", action="store_true",
+                    help="secondary measurement: fine-tune both encoders with the head (forward with saved activations + hand-written "
+                         "backward; the reference keeps its encoders frozen)")
     ap.add_argument("--dry-launch", action="store_true", help="--gpus N > 1 started plainly: print the torchrun command it would start, start nothing")
     args = ap.parse_args()
 
@@ -298,6 +361,8 @@ def main():
         return
     global SEQ_LEN, FRAMES
     SEQ_LEN, FRAMES = args.seq_len, args.frames       # (defaults = the headline configuration, BASELINE configs[1])
+    if args.train_encoders:
+        return bench_train_encoders(args, dev, world, rank)
     tenc = BertTextEncoder(fold_ln=not args.no_fold_ln, residual_dtype=args.residual_dtype).to(dev)    # BERT-base geometry, random init (no checkpoints offline)
     venc = ClipVisualEncoder(fold_ln=not args.no_fold_ln, residual_dtype=args.residual_dtype).to(dev)  # CLIP ViT-B/32 geometry, random init
     split = None

@@ -80,8 +80,8 @@ def test_vit_b32_8_frames_full_depth_vs_oracle(stream):
         assert e["rel_rms"] <= bound, (k, e)
 
 
-@pytest.mark.parametrize("off", [1.0, 20.0])
-def test_outlier_shaped_weights_full_depth_pass_folded_or_trip_the_guard(off):
+@pytest.mark.parametrize("off,stream", [(1.0, "fp32"), (1.0, "bf16"), (20.0, "bf16")])
+def test_outlier_shaped_weights_full_depth_pass_folded_or_trip_the_guard(off, stream):
     """12-layer BERT geometry with trained-model-like outliers: a few hidden dimensions carry 20x LayerNorm gains and EVERY
     LayerNorm bias adds a common-mode offset of `off` standard deviations, so the rows entering the next (folded) LayerNorm
     have |mean| / std ~ off.  off = 1: inside the guard's range, the folded encoder must hold the relative feature bounds;
@@ -100,7 +100,7 @@ def test_outlier_shaped_weights_full_depth_pass_folded_or_trip_the_guard(off):
             w[k] = w[k] + off
     ids, mask = E.synthetic_tokens(191, 4, 128, vocab=1000)
     ref = E.text_features(w, ids, mask)
-    enc = BertTextEncoder(layers=12, vocab_size=1000)
+    enc = BertTextEncoder(layers=12, vocab_size=1000, residual_dtype=stream)
     enc.load_state_dict(w)
     enc = enc.to(DEV)
     folded = enc(ids, mask).clone().cpu()
@@ -113,18 +113,23 @@ def test_outlier_shaped_weights_full_depth_pass_folded_or_trip_the_guard(off):
     mat = BertTextEncoder(layers=12, vocab_size=1000, fold_ln=False)           # the same weights with one LayerNorm kernel per LayerNorm
     mat.load_state_dict(w)
     em = feature_errors(mat.to(DEV)(ids, mask).clone().cpu(), ref)
-    print(f"outlier-shaped weights, offset {off}: guard ratio {ratio:.2f}; folded {e}; strict {es}; materialised {em}; "
+    print(f"outlier-shaped weights, offset {off}, {stream} stream: guard ratio {ratio:.2f}; folded {e}; strict {es}; materialised {em}; "
           f"folding {'kept' if enc.fold_ln else 'switched off'}")
-    # 20x gains on four dimensions amplify every bf16 rounding upstream of them: the MATERIALISED encoder's own error on these
-    # weights is the yardstick (measured with off = 1: rel-L2 1.3e-2, 1 - cos 8e-5, against 8.3e-3 / 3.5e-5 on ordinary weights);
-    # per-column outliers cost the folded and the materialised path the same, only a per-row offset separates them
-    near = lambda x: x["rel_l2"] <= 1.5 * em["rel_l2"] + 1e-3 and x["one_minus_cos"] <= 2.0 * em["one_minus_cos"] + 1e-5
-    assert em["rel_l2"] <= 3e-2 and em["one_minus_cos"] <= 2e-4, em
-    assert near(es), (es, em)                                                  # what a strict caller gets
-    if off <= 1.0:
-        assert ratio <= enc.FOLD_GUARD_MAX and enc.fold_ln and near(e), (ratio, e, em)
+    # Yardstick: the MATERIALISED encoder (fp32 stream, one LayerNorm kernel per LayerNorm) on the same weights (measured:
+    # rel-L2 4.6e-3, 1 - cos 1.0e-5).  Folding itself costs nothing on per-column outliers (fp32 stream: within 1.5x of the
+    # yardstick); the bf16 STREAM does -- the four hot dimensions carry values of ~20 whose bf16 rounding (0.04 absolute per
+    # layer) is then amplified by the next 20x gain: rel-L2 1.3e-2, 1 - cos 8.2e-5 measured, the price of keeping the stream in
+    # the operands' dtype (what bf16 inference of a trained BERT does with its outlier dimensions).  Bounds = 2 x measured.
+    assert em["rel_l2"] <= 1.0e-2 and em["one_minus_cos"] <= 2.5e-5, em
+    if stream == "fp32":
+        ok = lambda x: x["rel_l2"] <= 1.5 * em["rel_l2"] + 1e-3 and x["one_minus_cos"] <= 2.0 * em["one_minus_cos"] + 1e-5
     else:
-        assert ratio > enc.FOLD_GUARD_MAX and not enc.fold_ln, ratio           # tripped: the strict pass repeated the batch unfolded
+        ok = lambda x: x["rel_l2"] <= 2.6e-2 and x["one_minus_cos"] <= 1.7e-4
+    if off <= 1.0:
+        assert ratio <= enc.FOLD_GUARD_MAX and enc.fold_ln and ok(e) and ok(es), (ratio, e, es, em)
+    else:                                                                      # tripped: the strict pass repeated the batch unfolded (fp32 stream)
+        assert ratio > enc.FOLD_GUARD_MAX and not enc.fold_ln, ratio
+        assert es["rel_l2"] <= 1.5 * em["rel_l2"] + 1e-3, (es, em)
 
 
 def test_end_to_end_logits_full_geometry_B32():

@@ -57,25 +57,42 @@ __global__ __launch_bounds__(256) void transpose_kernel(const TIn* __restrict__ 
       if (c0 + (int)threadIdx.x < cols) part[(size_t)blockIdx.y * cols + c0 + threadIdx.x] = s;
     }
   }
-  // write: dst row = source column, 8 consecutive source rows per 16-B store
+  // write: dst row = source column, 8 consecutive source rows per 16-B store, transposed out of the tile by the hardware
+  // (ds_read_b64_tr_b16: a 16-lane group reads a 4-row x 16-column block, lane i receives column i of the 4 rows; lane 4q+p
+  // supplies the address of row q, columns 4p..4p+3).  Wave w takes source columns 16w..16w+15, group g row blocks 8g and 32+8g.
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15, q = i >> 2, pq = i & 3;
+  const int C = 16 * wave;
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const int oc = tr + 32 * p, orow = tc;             // output row c0 + oc, output columns r0 + orow .. + 7
-    if (c0 + oc < cols && r0 + orow < rows_pad) {
-      bf16x8 v;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = tile[orow + q][oc];
-      *reinterpret_cast<bf16x8*>(dst + (size_t)(c0 + oc) * ldd + r0 + orow) = v;
-    }
+  for (int it = 0; it < 2; ++it) {
+    const int R = 32 * it + 8 * g;
+    union { s16x4 s2[2]; bf16x8 v; } u;
+    u.s2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(&tile[R + q][C + 4 * pq]));
+    u.s2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(&tile[R + 4 + q][C + 4 * pq]));
+    if (c0 + C + i < cols && r0 + R < rows_pad) *reinterpret_cast<bf16x8*>(dst + (size_t)(c0 + C + i) * ldd + r0 + R) = u.v;
   }
 }
 
+// out[c] (+)= sum_t part[t][c].  16 columns x 16 row-groups per block: group j adds rows j, j + 16, ... in ascending order, the
+// groups combine in a fixed tree -- enough blocks in flight for a (tiles x cols) panel of a few MB (3 blocks of 256 serial
+// adders took 12 us per call), and still one fixed order of additions.
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int tiles, int cols, float* __restrict__ out, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
+  __shared__ float sh[16][17];
+  const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
   float s = 0.f;
-  for (int t = 0; t < tiles; ++t) s += part[(size_t)t * cols + c];
-  out[c] = accumulate ? out[c] + s : s;
+  if (c < cols)
+    for (int t = grp; t < tiles; t += 16) s += part[(size_t)t * cols + c];
+  sh[grp][cl] = s;
+  __syncthreads();
+  if (grp == 0 && c < cols) {
+    float a[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k] = sh[k][cl];
+#pragma unroll
+    for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+      for (int k = 0; k < w; ++k) a[k] += a[k + w];
+    out[c] = accumulate ? out[c] + a[0] : a[0];
+  }
 }
 
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int nslab, size_t slab_stride, size_t n, float* __restrict__ out,
@@ -190,7 +207,7 @@ extern "C" int ufnd_transpose_bf16(const void* src, int src_is_f32, int rows, in
                        colsum ? colsum_ws : (float*)nullptr);
   UFND_CHECK_LAUNCH();
   if (colsum) {
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3(ufnd_cdiv(cols, 256)), dim3(256), 0, stream, colsum_ws, (int)grid.y, cols, colsum, colsum_accumulate);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(ufnd_cdiv(cols, 16)), dim3(256), 0, stream, colsum_ws, (int)grid.y, cols, colsum, colsum_accumulate);
     UFND_CHECK_LAUNCH();
   }
   return UFND_OK;
