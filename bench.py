@@ -286,6 +286,8 @@ def main():
                     help="encoders' residual stream: fp32 beside the bf16 operands, or the bf16 rounding itself (encoders.py)")
     ap.add_argument("--head-only", action="store_true",
                     help="secondary measurement: the reference's actual training mode (cached features, no encoders in the step)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="under torchrun at world 1: run the bucketed gradient exchange anyway (the RCCL path's fixed cost on one GPU)")
     ap.add_argument("--train-encoders", action="store_true",
                     help="secondary measurement: fine-tune both encoders with the head (forward with saved activations + hand-written "
                          "backward; the reference keeps its encoders frozen)")
@@ -321,7 +323,7 @@ def main():
     if args.head_only:
         cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir="/tmp/ufnd_bench", batch_size=B, device=str(dev),
                           use_graph=not args.no_graph, seed=42)
-        tr = ForensicTrainer(cfg, cache=synthetic_cache(max(64, 8 * B), seed=1))
+        tr = ForensicTrainer(cfg, cache=synthetic_cache(max(64, 8 * B), seed=1), force_exchange=args.force_exchange)
         tr.fusion.train(); tr.clf.train()
         from ultrafnd_git_amd.trainer import IndexedBatch
         ds = tr.train_loader.dataset            # batches as the loader yields them: row indices of the HBM-resident split
@@ -376,7 +378,8 @@ def main():
         if spec:
             enc.tiles = {k: int(v) for k, v in (kv.split("=") for kv in spec.split(","))}
     tsync = TemporalSyncNet(in_dim=768, out_dim=256).to(dev)   # temporal = align(text, visual), as the cache builder does
-    tr = ForensicTrainer(cfg, cache=synthetic_cache(64, seed=1), text_encoder=tenc, visual_encoder=venc, temporal_net=tsync)
+    tr = ForensicTrainer(cfg, cache=synthetic_cache(64, seed=1), text_encoder=tenc, visual_encoder=venc, temporal_net=tsync,
+                         force_exchange=args.force_exchange)
     tr.fusion.train()
     tr.clf.train()
     G = max(1, args.lookahead)

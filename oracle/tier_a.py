@@ -34,13 +34,14 @@ TREES, DEPTH, TAU = 6, 4, 10.0
 NUM_CLASSES = 2
 
 
-def fusion_shapes(hidden: int = HIDDEN, gnn_dim: int = GNN_DIM) -> "OrderedDict[str, Tuple[int, ...]]":
+def fusion_shapes(hidden: int = HIDDEN, gnn_dim: int = GNN_DIM, use_gnn: bool = True) -> "OrderedDict[str, Tuple[int, ...]]":
     """state_dict key -> shape, in the reference's registration order
-    (cross_modal_transformer.py:96-130; semantic.* from semantic_forgery.py:73-82)."""
+    (cross_modal_transformer.py:96-130; semantic.* from semantic_forgery.py:73-82).  use_gnn=False is fusion.yaml's
+    `use_gnn: false`: no gnn_proj, fuse_mlp.0 is 15H wide (:88,101-102,114-120)."""
     H = hidden
     s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
     for name, d in (("text", TEXT_DIM), ("audio", AUDIO_DIM), ("visual", VISUAL_DIM),
-                    ("temporal", TEMPORAL_DIM), ("gnn", gnn_dim)):
+                    ("temporal", TEMPORAL_DIM)) + ((("gnn", gnn_dim),) if use_gnn else ()):
         s[f"{name}_proj.weight"] = (H, d)
         s[f"{name}_proj.bias"] = (H,)
     for name in ("text_proj", "vision_proj"):
@@ -54,7 +55,7 @@ def fusion_shapes(hidden: int = HIDDEN, gnn_dim: int = GNN_DIM) -> "OrderedDict[
         s[f"{blk}.evidence_proj.0.bias"] = (H,)
         s[f"{blk}.evidence_proj.2.weight"] = (1, H)
         s[f"{blk}.evidence_proj.2.bias"] = (1,)
-    s["fuse_mlp.0.weight"] = (2 * H, 16 * H)
+    s["fuse_mlp.0.weight"] = (2 * H, (16 if use_gnn else 15) * H)
     s["fuse_mlp.0.bias"] = (2 * H,)
     s["fuse_mlp.3.weight"] = (H, 2 * H)
     s["fuse_mlp.3.bias"] = (H,)
@@ -94,7 +95,7 @@ def no_grad_keys_clf():
     return ["temperature"] + [f"node.trees.{t}.tau" for t in range(TREES)]
 
 
-def seeded_params(seed: int) -> Tuple[Dict[str, torch.Tensor], Dict[str, torch.Tensor]]:
+def seeded_params(seed: int, use_gnn: bool = True) -> Tuple[Dict[str, torch.Tensor], Dict[str, torch.Tensor]]:
     """Deterministic, *perturbed* parameters (NODE leaves/gates non-zero so the
     tree path is exercised -- SURVEY.md 8c).  Regenerated from the seed on both
     sides of every comparison so fixtures stay small; a checksum of the result is
@@ -116,7 +117,7 @@ def seeded_params(seed: int) -> Tuple[Dict[str, torch.Tensor], Dict[str, torch.T
             return torch.randn(shape, generator=g) * (1.0 / math.sqrt(shape[1]))
         return torch.randn(shape, generator=g) * 0.05
 
-    fus = OrderedDict((k, gen(k, s)) for k, s in fusion_shapes().items())
+    fus = OrderedDict((k, gen(k, s)) for k, s in fusion_shapes(use_gnn=use_gnn).items())
     clf = OrderedDict((k, gen(k, s)) for k, s in clf_shapes().items())
     return fus, clf
 
@@ -179,7 +180,7 @@ def fusion_forward(p: Dict[str, torch.Tensor], feats: Dict[str, torch.Tensor],
 
     pairs = [t + a, t * a, (t - a).abs(), t + v, t * v, (t - v).abs(), t + u, v + u]  # :172-178
     cat = [t, a, v, u, *pairs, tv, ta, vu]
-    if feats.get("gnn_feat") is not None:  # :184-187
+    if feats.get("gnn_feat") is not None and "gnn_proj.weight" in p:  # :184-187 (`use_gnn: false`: no gnn_proj, gnn_feat ignored)
         cat.append(F.linear(feats["gnn_feat"].float(), p["gnn_proj.weight"], p["gnn_proj.bias"]))
     fused_cat = torch.cat(cat, dim=-1)
 

@@ -171,6 +171,66 @@ def tier_a():
 
 
 # ---------------------------------------------------------------------------
+def tier_a_nognn():
+    """fusion.yaml `use_gnn: false` (15H concat, no gnn_proj; cross_modal_transformer.py:88,101-102,114-120): the reference's own
+    module built from such a YAML, eval forward + one backward, against the oracle -> tier_a_nognn_B4.npz."""
+    sys.modules["transformers"] = None
+    os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, str(REF))
+    yaml_path = str(REPO / "configs" / "model_configs" / "fusion_nognn.yaml")
+    os.chdir(REF)
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from src.models.fusion.cross_modal_transformer import CrossModalTransformer
+    from src.models.fusion.deep_truth_classifier import DeepTruthClassifier
+    from oracle import tier_a as O
+    B, bseed = 4, 29
+    fus_sd, clf_sd = O.seeded_params(PARAM_SEED + 1, use_gnn=False)
+    torch.manual_seed(0)
+    fusion = CrossModalTransformer(yaml_path).to("cpu")
+    clf = DeepTruthClassifier("configs/model_configs/classifier.yaml").to("cpu")
+    assert not fusion.use_gnn and fusion.fused_dim == 15 * 512 and not hasattr(fusion, "gnn_proj")
+    assert list(fusion.state_dict().keys()) == list(fus_sd.keys())
+    fusion.load_state_dict(fus_sd); clf.load_state_dict(clf_sd)
+    for m in list(fusion.modules()) + list(clf.modules()):
+        if isinstance(m, nn.Dropout):
+            m.p = 0.0
+    batch = O.seeded_batch(bseed, B)
+    feats = {k: batch[k] for k in ("text_features", "audio_features", "visual_features", "temporal_features", "gnn_feat")}   # gnn_feat given: must be ignored
+    store = {"param_seed": np.int64(PARAM_SEED + 1), "batch_seed": np.int64(bseed),
+             "param_checksum": np.float64(sum(v.double().sum() for v in list(fus_sd.values()) + list(clf_sd.values())))}
+    fusion.eval(); clf.eval()
+    with torch.no_grad():
+        fo = fusion(feats)
+        co = clf(fo["fused"], batch["aux"])
+    oo = O.forward_batch(fus_sd, clf_sd, batch, train=False)
+    for name, r, o in (("fused", fo["fused"], oo["fused"]), ("logits", co["logits"], oo["logits"]), ("probs", co["probs"], oo["probs"])):
+        assert (r - o).abs().max().item() <= 1e-6, name
+        store[f"out/{name}"] = r.numpy()
+    fusion.train(); clf.train()
+    fo = fusion(feats)
+    co = clf(fo["fused"], batch["aux"])
+    loss = F.cross_entropy(co["logits"], batch["label"])
+    loss.backward()
+    _, oloss, gf, gc = O.loss_and_grads(fus_sd, clf_sd, batch, train=False)
+    assert abs(float(oloss) - loss.item()) <= 1e-6
+    nograd = []
+    for pre, mod, og in (("fusion.", fusion, gf), ("clf.", clf, gc)):
+        for k, p in mod.named_parameters():
+            g = og[k]
+            assert (g is None) == (p.grad is None), k
+            if p.grad is None:
+                nograd.append(pre + k)
+            else:
+                assert (g - p.grad).abs().max().item() <= 2e-6 * max(1.0, p.grad.abs().max().item()), k
+                put_digest(store, f"grad/{pre}{k}", p.grad)
+    store["nograd_keys"] = np.array(json.dumps(nograd))
+    store["step1/loss"] = np.float64(loss.item())
+    np.savez_compressed(HERE / "tier_a_nognn_B4.npz", **store)
+    print(f"tier_a_nognn B={B}: ok  loss={loss.item():.6f}  ({len(nograd)} tensors without gradient)")
+
+
 def metrics():
     sys.modules["transformers"] = None
     sys.dont_write_bytecode = True
@@ -597,7 +657,7 @@ def gnn_model():
 if __name__ == "__main__":
     part = sys.argv[1] if len(sys.argv) > 1 else "all"
     if part == "all":
-        for p in ("tier_a", "metrics", "tier_b", "tier_b_grads", "temporal", "temporal_seq", "init_parity", "gcn", "gnn_model"):
+        for p in ("tier_a", "tier_a_nognn", "metrics", "tier_b", "tier_b_grads", "temporal", "temporal_seq", "init_parity", "gcn", "gnn_model"):
             subprocess.check_call([sys.executable, str(Path(__file__).resolve()), p], cwd=str(REPO))
     else:
-        {"tier_a": tier_a, "metrics": metrics, "tier_b": tier_b, "tier_b_grads": tier_b_grads, "temporal": temporal, "temporal_seq": temporal_seq, "init_parity": init_parity, "gcn": gcn, "gnn_model": gnn_model}[part]()
+        {"tier_a": tier_a, "tier_a_nognn": tier_a_nognn, "metrics": metrics, "tier_b": tier_b, "tier_b_grads": tier_b_grads, "temporal": temporal, "temporal_seq": temporal_seq, "init_parity": init_parity, "gcn": gcn, "gnn_model": gnn_model}[part]()

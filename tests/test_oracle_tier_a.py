@@ -79,3 +79,26 @@ def test_missing_gnn_feat_changes_width():
     b["gnn_feat"] = None
     with pytest.raises(RuntimeError):
         O.fusion_forward(fus, b)
+
+
+def test_oracle_without_the_gnn_slot_matches_the_reference_fixture():
+    """fusion.yaml `use_gnn: false`: the oracle's 15H head against the outputs of the reference's own module built from such a
+    YAML (tests/golden/tier_a_nognn_B4.npz; make_golden.py tier_a_nognn)."""
+    import numpy as np
+    from tests.helpers import assert_digest_close, load_npz, nograd_keys
+    from oracle import tier_a as O
+    z = load_npz("tier_a_nognn_B4.npz")
+    fus, clf = O.seeded_params(int(z["param_seed"]), use_gnn=False)
+    assert "gnn_proj.weight" not in fus and tuple(fus["fuse_mlp.0.weight"].shape) == (1024, 7680)
+    assert abs(float(sum(v.double().sum() for v in list(fus.values()) + list(clf.values()))) - float(z["param_checksum"])) < 1e-6
+    batch = O.seeded_batch(int(z["batch_seed"]), 4)
+    out = O.forward_batch(fus, clf, batch, train=False)
+    for name in ("fused", "logits", "probs"):
+        assert np.abs(out[name].numpy() - z[f"out/{name}"]).max() <= 1e-6, name
+    _, loss, gf, gc = O.loss_and_grads(fus, clf, batch, train=False)
+    assert abs(float(loss) - float(z["step1/loss"])) <= 1e-6
+    grads = {**{"fusion." + k: g for k, g in gf.items()}, **{"clf." + k: g for k, g in gc.items()}}
+    assert sorted(k for k, g in grads.items() if g is None) == sorted(nograd_keys(z))
+    for k, g in grads.items():
+        if g is not None:
+            assert_digest_close(z, f"grad/{k}", g, rtol=1e-5, atol=1e-9)

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void nn_kernel(const NnArgs args) {
     const int mrow = m0 + q + 8 * w + 4 * h;
     if (mrow >= P.M || !kok) continue;
     if (P.nsplit > 1) {
-      float* dst = P.out + ((size_t)ns * P.M + mrow) * P.K + kcol;
+      float* dst = P.out + ((size_t)ns * P.M + mrow) * P.ldo + kcol;      // partials [nsplit][M][ldo] (the one caller has ldo == K or the consumer's row stride)
 #pragma unroll
       for (int v = 0; v < VEC; ++v) dst[v] = val[v];
       continue;

@@ -25,7 +25,7 @@ int launch_nt(const NtProb* probs, int nprob, const ufnd_step_state* st, hipStre
 struct NnProb {
   const float* dY;    // (M, N) row stride lddy (lddy % 4 == 0)
   const float* W;     // (N, K) row stride ldw
-  float* out;         // (M, K) row stride ldo; when nsplit > 1: partials [nsplit][M][K]
+  float* out;         // (M, K) row stride ldo; when nsplit > 1: partials [nsplit][M] rows of stride ldo
   const float* actZ;  // optional (M, K) row stride ldz
   const float* add;   // optional (M, K) row stride ldadd
   int M, N, K, lddy, ldw, ldo, ldz, ldadd;

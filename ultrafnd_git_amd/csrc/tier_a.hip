@@ -769,7 +769,8 @@ extern "C" int ufnd_fusion_forward(const ufnd_dims* d, const ufnd_fusion_params*
                                    float* forensic, const ufnd_step_state* state, void* stream_) {
   TRY(check_dims(d, B));
   UFND_REQUIRE(p && text && audio && visual && temporal && workspace && fused && forensic && state, "fusion_forward: null argument");
-  UFND_REQUIRE(gnn, "fusion_forward: gnn_feat is required (fuse_mlp expects the 16*hidden concat, cross_modal_transformer.py:184-195)");
+  UFND_REQUIRE(gnn || d->gnn_dim == 0, "fusion_forward: gnn_feat is required when dims.gnn_dim > 0 (fuse_mlp then expects the 16*hidden concat, "
+               "cross_modal_transformer.py:184-195); gnn_dim == 0 is fusion.yaml's `use_gnn: false` (15*hidden, no gnn_proj)");
   UFND_REQUIRE(ld_fused % 4 == 0 && ld_fused >= d->hidden && ufnd_aligned(fused, 16) && ufnd_aligned(workspace, 256),
                "fusion_forward: fused/workspace alignment");
   hipStream_t stream = (hipStream_t)stream_;
@@ -778,7 +779,9 @@ extern "C" int ufnd_fusion_forward(const ufnd_dims* d, const ufnd_fusion_params*
   const float drop = train ? d->fusion_dropout : 0.0f;
   const dim3 rows(ufnd_cdiv(B, 4)), blk(256);
 
-  // 1. five projections straight into their CAT slots                          (:147-150,184-187)
+  // fusion.yaml `use_gnn: false` (dims.gnn_dim == 0): no gnn_proj, the concat is the first 15 slots (:88,101-102,119-120)
+  const int NPROJ = d->gnn_dim > 0 ? 5 : 4, CW = (d->gnn_dim > 0 ? 16 : 15) * H;
+  // 1. the projections straight into their CAT slots                          (:147-150,184-187)
   {
     const float* xs[5] = {text, audio, visual, temporal, gnn};
     const float* ws_[5] = {p->text_w, p->audio_w, p->visual_w, p->temporal_w, p->gnn_w};
@@ -786,10 +789,10 @@ extern "C" int ufnd_fusion_forward(const ufnd_dims* d, const ufnd_fusion_params*
     const int ks[5] = {d->text_dim, d->audio_dim, d->visual_dim, d->temporal_dim, d->gnn_dim};
     const int slot[5] = {0, 1, 2, 3, 15};
     NtProb pr[5];
-    for (int i = 0; i < 5; ++i)
+    for (int i = 0; i < NPROJ; ++i)
       pr[i] = NtProb{xs[i], ws_[i], bs[i], w.cat + (size_t)slot[i] * H, nullptr, B, H, ks[i], ks[i], ks[i], 16 * H, 0,
                      0, 0.0f, 0, 1};
-    TRY(launch_nt(pr, 5, state, stream));
+    TRY(launch_nt(pr, NPROJ, state, stream));
   }
   // 2. stacked q/k/v projections: t -> [q_tv q_ta], v -> [k_tv v_tv q_vu], a -> [k_ta v_ta], u -> [k_vu v_vu]
   {
@@ -810,7 +813,7 @@ extern "C" int ufnd_fusion_forward(const ufnd_dims* d, const ufnd_fusion_params*
   UFND_CHECK_LAUNCH();
   // 4. fuse_mlp.0: (B,16H) x (2H,16H)^T, split-K then bias+GELU(+dropout)             (:122-124)
   {
-    NtProb pr{w.cat, p->fuse0_w, nullptr, w.part1, nullptr, B, 2 * H, 16 * H, 16 * H, 16 * H, 2 * H, 0, 0, 0.0f, 0,
+    NtProb pr{w.cat, p->fuse0_w, nullptr, w.part1, nullptr, B, 2 * H, CW, 16 * H, CW, 2 * H, 0, 0, 0.0f, 0,
               KSPLIT_FUSE0};
     TRY(launch_nt(&pr, 1, state, stream));
     const int n4 = B * 2 * H / 4;
@@ -840,7 +843,7 @@ extern "C" int ufnd_fusion_backward_phase(const ufnd_dims* d, const ufnd_fusion_
   TRY(check_dims(d, B));
   UFND_REQUIRE(phase == UFND_BWD_ALL || phase == UFND_BWD_FUSE_MLP || phase == UFND_BWD_REST, "fusion_backward: phase=%d", phase);
   const bool do_head = phase != UFND_BWD_REST, do_rest = phase != UFND_BWD_FUSE_MLP;
-  UFND_REQUIRE(p && g && text && audio && visual && temporal && gnn && workspace && state, "fusion_backward: null argument");
+  UFND_REQUIRE(p && g && text && audio && visual && temporal && (gnn || (d && d->gnn_dim == 0)) && workspace && state, "fusion_backward: null argument");
   UFND_REQUIRE(!do_head || d_fused || d_logits, "fusion_backward: no incoming gradient");
   hipStream_t stream = (hipStream_t)stream_;
   const ForkJoin fj{stream, (hipStream_t)side_stream_};
@@ -873,8 +876,9 @@ extern "C" int ufnd_fusion_backward_phase(const ufnd_dims* d, const ufnd_fusion_
   }
   // fuse_mlp.0: dW (the 33.5 MB gradient), db; dCAT partials
   {
-    tn[ntn++] = TnProb{w.dz1, w.cat, g->fuse0_w, g->fuse0_b, B, 2 * H, 16 * H, 2 * H, 16 * H, 16 * H};
-    NnProb n{w.dz1, p->fuse0_w, w.dcatp, nullptr, nullptr, B, 2 * H, 16 * H, 2 * H, 16 * H, 16 * H, 0, 0, 0.0f, 0, 0,
+    const int CW = (d->gnn_dim > 0 ? 16 : 15) * H;      // (use_gnn: false: 15 slots; CAT / dCAT keep their 16H row stride)
+    tn[ntn++] = TnProb{w.dz1, w.cat, g->fuse0_w, g->fuse0_b, B, 2 * H, CW, 2 * H, 16 * H, CW};
+    NnProb n{w.dz1, p->fuse0_w, w.dcatp, nullptr, nullptr, B, 2 * H, CW, 2 * H, CW, 16 * H, 0, 0, 0.0f, 0, 0,
              NSPLIT_FUSE0};
     if (phase == UFND_BWD_FUSE_MLP) {
       // bucketed gradient exchange: the two fuse_mlp weight gradients (67 % of all gradient bytes) are written NOW,
@@ -927,7 +931,7 @@ extern "C" int ufnd_fusion_backward_phase(const ufnd_dims* d, const ufnd_fusion_
     float* gb[5] = {g->text_b, g->audio_b, g->visual_b, g->temporal_b, g->gnn_b};
     const int ks[5] = {d->text_dim, d->audio_dim, d->visual_dim, d->temporal_dim, d->gnn_dim};
     const float* dys[5] = {w.dtavu, w.dtavu + (size_t)B * H, w.dtavu + (size_t)2 * B * H, w.dtavu + (size_t)3 * B * H, w.dg};
-    for (int i = 0; i < 5; ++i) tn[ntn++] = TnProb{dys[i], xs[i], gw[i], gb[i], B, H, ks[i], H, ks[i], ks[i]};
+    for (int i = 0; i < (d->gnn_dim > 0 ? 5 : 4); ++i) tn[ntn++] = TnProb{dys[i], xs[i], gw[i], gb[i], B, H, ks[i], H, ks[i], ks[i]};
     TRY(launch_tn(tn, ntn, fj.dw()));
   }
   }  // do_rest

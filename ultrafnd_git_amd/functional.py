@@ -39,7 +39,7 @@ class FusionFunction(torch.autograd.Function):
         forensic = torch.empty(3, B, dtype=torch.float32, device=dev)
         d = module.dims()
         L.check(L.lib().ufnd_fusion_forward(C.byref(d), C.byref(module.param_table()), text.data_ptr(),
-                                            audio.data_ptr(), visual.data_ptr(), temporal.data_ptr(), gnn.data_ptr(),
+                                            audio.data_ptr(), visual.data_ptr(), temporal.data_ptr(), gnn.data_ptr() if gnn.numel() else None,
                                             B, int(bool(train)), ws.data_ptr(), fused.data_ptr(), H, logits.data_ptr(),
                                             forensic.data_ptr(), state.ptr, L.stream_ptr(dev)), "ufnd_fusion_forward")
         ctx.set_materialize_grads(False)
@@ -72,7 +72,7 @@ class FusionFunction(torch.autograd.Function):
         df = L.f32c(d_fused) if d_fused is not None else None
         dl = L.f32c(d_logits) if d_logits is not None else None
         L.check(L.lib().ufnd_fusion_backward(C.byref(d), C.byref(module.param_table()), C.byref(gt), text.data_ptr(),
-                                             audio.data_ptr(), visual.data_ptr(), temporal.data_ptr(), gnn.data_ptr(),
+                                             audio.data_ptr(), visual.data_ptr(), temporal.data_ptr(), gnn.data_ptr() if gnn.numel() else None,
                                              ctx.B, int(ctx.train), module.workspace(ctx.B, True).data_ptr(), L.ptr(df),
                                              H, L.ptr(dl), module.rng().ptr, L.stream_ptr(dev), None, 1), "ufnd_fusion_backward")
         _bind_grads(module)

@@ -63,22 +63,20 @@ class CrossModalTransformer(ArenaModule):
         self.use_gnn = bool(cfg.get("use_gnn", True))
         self.gnn_dim = int(cfg.get("gnn_dim", 128))
         self.dtype = torch.float32
-        if not self.use_gnn:
-            raise ValueError("use_gnn=false is not supported by the HIP path: the reference's fuse_mlp is sized "
-                             "for the concat including the GNN slot only when use_gnn is true")
         H = self.hidden
         # construction order == the reference's (:96-130) so the RNG stream matches
         self.text_proj = nn.Linear(768, H)
         self.audio_proj = nn.Linear(128, H)
         self.visual_proj = nn.Linear(512, H)
         self.temporal_proj = nn.Linear(256, H)
-        self.gnn_proj = nn.Linear(self.gnn_dim, H)
+        if self.use_gnn:           # `use_gnn: false` (:88,101-102): no gnn_proj, the concat is 15H wide, gnn_feat is ignored
+            self.gnn_proj = nn.Linear(self.gnn_dim, H)
         self.semantic = _SemanticParams()
         self.attn_tv = ForensicCoAttention(H, 3)
         self.attn_ta = ForensicCoAttention(H, 3)
         self.attn_vu = ForensicCoAttention(H, 3)
         self.include_pairs = True
-        self.fused_dim = 16 * H
+        self.fused_dim = (16 if self.use_gnn else 15) * H        # (:114-120)
         self.fuse_mlp = nn.Sequential(nn.Linear(self.fused_dim, 2 * H), nn.GELU(), nn.Dropout(self.dropout),
                                       nn.Linear(2 * H, H), nn.GELU(), nn.Dropout(self.dropout))
         self.classifier = nn.Linear(H, 2)
@@ -92,7 +90,7 @@ class CrossModalTransformer(ArenaModule):
     # ------------------------------------------------------------------ arena layout
     def _arena_groups(self) -> Tuple[List[Group], List[Group]]:
         H = self.hidden
-        fuse = [("fuse_mlp.0.weight", (2 * H, 16 * H)), ("fuse_mlp.0.bias", (2 * H,)),
+        fuse = [("fuse_mlp.0.weight", (2 * H, self.fused_dim)), ("fuse_mlp.0.bias", (2 * H,)),
                 ("fuse_mlp.3.weight", (H, 2 * H)), ("fuse_mlp.3.bias", (H,))]
         qkv_w = [(f"{b}.{p}.weight", (H, H)) for b, p in _QKV_ORDER]
         qkv_b = [(f"{b}.{p}.bias", (H,)) for b, p in _QKV_ORDER]
@@ -101,7 +99,7 @@ class CrossModalTransformer(ArenaModule):
             ev += [(f"{b}.evidence_proj.0.weight", (H, 3)), (f"{b}.evidence_proj.0.bias", (H,)),
                    (f"{b}.evidence_proj.2.weight", (1, H)), (f"{b}.evidence_proj.2.bias", (1,))]
         proj = []
-        for n, d in _PROJ + (("gnn", self.gnn_dim),):
+        for n, d in _PROJ + ((("gnn", self.gnn_dim),) if self.use_gnn else ()):
             proj += [(f"{n}_proj.weight", (H, d)), (f"{n}_proj.bias", (H,))]
         # gradient-ready order of backward: fuse_mlp first, then attention, then projections
         grad = [fuse, qkv_w, qkv_b] + [[e] for e in ev] + [[p] for p in proj]
@@ -119,13 +117,13 @@ class CrossModalTransformer(ArenaModule):
     def dims(self, clf=None) -> L.Dims:
         d = L.Dims()
         d.hidden, d.text_dim, d.audio_dim, d.visual_dim, d.temporal_dim = self.hidden, 768, 128, 512, 256
-        d.gnn_dim, d.aux_dim, d.trees, d.depth, d.classes = self.gnn_dim, 2, 6, 4, 2
+        d.gnn_dim, d.aux_dim, d.trees, d.depth, d.classes = (self.gnn_dim if self.use_gnn else 0), 2, 6, 4, 2      # gnn_dim 0 = no GNN slot
         d.fusion_dropout, d.clf_dropout, d.node_dropout = self.dropout, 0.1, 0.3
         return d
 
     def _table(self, getter) -> L.FusionParams:
         t = L.FusionParams()
-        for n in ("text", "audio", "visual", "temporal", "gnn"):
+        for n in ("text", "audio", "visual", "temporal") + (("gnn",) if self.use_gnn else ()):
             setattr(t, f"{n}_w", getter(f"{n}_proj.weight").data_ptr())
             setattr(t, f"{n}_b", getter(f"{n}_proj.bias").data_ptr())
         t.qkv_w = getter("attn_tv.q.weight").data_ptr()
@@ -176,12 +174,13 @@ class CrossModalTransformer(ArenaModule):
         if dev.type != "cuda":
             raise L.UltrafndHipError("CrossModalTransformer runs on a HIP device only: call .to('cuda') "
                                      "(there is no CPU fallback; the reference's CPU path is not part of this package)")
-        if feats.get("gnn_feat") is None:
+        if self.use_gnn and feats.get("gnn_feat") is None:
             raise RuntimeError("gnn_feat is required: fuse_mlp expects the 16*hidden concat "
                                "(the reference fails the same way without it, cross_modal_transformer.py:184-197)")
-        xs = [L.f32c(feats[k].to(dev)) for k in ("text_features", "audio_features", "visual_features",
-                                                 "temporal_features", "gnn_feat")]
-        for x, (n, dim) in zip(xs, _PROJ + (("gnn", self.gnn_dim),)):
+        xs = [L.f32c(feats[k].to(dev)) for k in ("text_features", "audio_features", "visual_features", "temporal_features")]
+        # use_gnn false: gnn_feat is ignored as in the reference (:184); a zero-width placeholder keeps the Function's arity
+        xs.append(L.f32c(feats["gnn_feat"].to(dev)) if self.use_gnn else torch.empty(xs[0].shape[0], 0, dtype=torch.float32, device=dev))
+        for x, (n, dim) in zip(xs, _PROJ + (("gnn", self.gnn_dim if self.use_gnn else 0),)):
             if x.dim() != 2 or x.shape[1] != dim or x.shape[0] != xs[0].shape[0]:
                 raise RuntimeError(f"{n} features: expected (B,{dim}), got {tuple(x.shape)}")
         from .functional import FusionFunction

@@ -153,6 +153,9 @@ class ForensicTrainer:
 
         self.fusion = CrossModalTransformer(config_path="configs/model_configs/fusion.yaml").to(self.device)
         self.clf = DeepTruthClassifier(config_path="configs/model_configs/classifier.yaml").to(self.device)
+        if not self.fusion.use_gnn:
+            raise ValueError("configs/model_configs/fusion.yaml says use_gnn: false while TrainConfig.use_gnn is true: the trainer would feed "
+                             "gnn_feat to a head without the GNN slot (the reference silently ignores it; set use_gnn in both places alike)")
         # trainable encoders: their masters join the arena behind the head's, in gradient-ready order (text, then visual)
         self.text_bp = self.vis_bp = None
         extra = []
