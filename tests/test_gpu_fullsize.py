@@ -82,10 +82,11 @@ def test_vit_b32_8_frames_full_depth_vs_oracle(stream):
 
 @pytest.mark.parametrize("off,stream", [(1.0, "fp32"), (1.0, "bf16"), (20.0, "bf16")])
 def test_outlier_shaped_weights_full_depth_pass_folded_or_trip_the_guard(off, stream):
-    """12-layer BERT geometry with trained-model-like outliers: a few hidden dimensions carry 20x LayerNorm gains and EVERY
-    LayerNorm bias adds a common-mode offset of `off` standard deviations, so the rows entering the next (folded) LayerNorm
-    have |mean| / std ~ off.  off = 1: inside the guard's range, the folded encoder must hold the relative feature bounds;
-    off = 20: beyond FOLD_GUARD_MAX, the guard must trip and the strict forward (materialised LayerNorms) must hold them.  (Real BERT / CLIP activation outliers are per-COLUMN -- they cost the folded and the materialised
+    """12-layer BERT geometry with trained-model-like outliers: a few hidden dimensions carry 20x LayerNorm gains.  off = 1:
+    every LayerNorm bias adds a common-mode offset of one standard deviation (rows entering the folded LayerNorms at
+    |mean| / std ~ 0.6): inside the guard's range, the folded encoder must hold the relative feature bounds.  off = 20: the
+    embedding LayerNorm's offset reaches layer 0's folded LayerNorm almost unchanged (|mean| / std beyond FOLD_GUARD_MAX): the
+    guard must trip and the strict forward (materialised LayerNorms) must hold the bounds.  (Real BERT / CLIP activation outliers are per-COLUMN -- they cost the folded and the materialised
     path the same; only a per-ROW offset separates them)"""
     from tests.helpers import feature_errors
     from oracle import encoders_ref as E
@@ -96,8 +97,11 @@ def test_outlier_shaped_weights_full_depth_pass_folded_or_trip_the_guard(off, st
         if k.endswith("LayerNorm.weight"):
             w[k] = w[k].clone()
             w[k][hot] *= 20.0
-        if k.endswith("LayerNorm.bias"):
+        if k.endswith("LayerNorm.bias") and off <= 1.0:
             w[k] = w[k] + off
+    if off > 1.0:        # a row offset that SURVIVES to a folded LayerNorm's input: embedding rows + off with a nearly silent attention branch
+        w["embeddings.LayerNorm.bias"] = w["embeddings.LayerNorm.bias"] + off
+        w["encoder.layer.0.attention.output.dense.weight"] = w["encoder.layer.0.attention.output.dense.weight"] * 0.01
     ids, mask = E.synthetic_tokens(191, 4, 128, vocab=1000)
     ref = E.text_features(w, ids, mask)
     enc = BertTextEncoder(layers=12, vocab_size=1000, residual_dtype=stream)
@@ -120,7 +124,7 @@ def test_outlier_shaped_weights_full_depth_pass_folded_or_trip_the_guard(off, st
     # yardstick); the bf16 STREAM does -- the four hot dimensions carry values of ~20 whose bf16 rounding (0.04 absolute per
     # layer) is then amplified by the next 20x gain: rel-L2 1.3e-2, 1 - cos 8.2e-5 measured, the price of keeping the stream in
     # the operands' dtype (what bf16 inference of a trained BERT does with its outlier dimensions).  Bounds = 2 x measured.
-    assert em["rel_l2"] <= 1.0e-2 and em["one_minus_cos"] <= 2.5e-5, em
+    assert em["rel_l2"] <= 2.0e-2 and em["one_minus_cos"] <= 1.0e-4, em          # (measured 4.6e-3 / 1.0e-5 at off = 1, 9.7e-3 / 4.7e-5 at off = 20)
     if stream == "fp32":
         ok = lambda x: x["rel_l2"] <= 1.5 * em["rel_l2"] + 1e-3 and x["one_minus_cos"] <= 2.0 * em["one_minus_cos"] + 1e-5
     else:

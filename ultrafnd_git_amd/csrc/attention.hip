@@ -16,7 +16,7 @@
 //        by ds_read_b64_tr_b16 (hardware transpose): 4 keys x 16 d per 16-lane group.
 // Masking follows HF: masked keys get the constant finfo.min-like score (a fully masked row
 // degenerates to a uniform average, not NaN); keys beyond L contribute exactly zero.
-#include "common.hpp"
+#include "attn_softmax.hpp"
 
 // No implicit contraction: the fused projection + attention kernel (gemm_bf16_kernel.hpp, ATT) repeats this kernel's
 // arithmetic operation for operation and must produce the same bits; fused multiply-adds are spelled out.
@@ -31,18 +31,23 @@ __device__ __forceinline__ bf16x8 k_frag(const char* tile, int row, int chunk) {
   return *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
 }
 
-// KB = keys per block (64: ~216 registers -> two workgroups per CU; 128: fewer softmax rescales)
+// KB = keys per block (64: 162 registers, three workgroups per CU; 128: 240 registers, two -- measured at L = 512, B = 128 in round 3:
+// 218 against 211 us per launch, not selected)
 // NW = waves per workgroup (32 queries each).  Sequences of <= 64 tokens (ViT-B/32: 50) run with NW = 2: the 4-wave form spends
 // half its waves on clamped duplicate queries there, and its 216 registers allow 8 waves per CU either way -- twice the
 // samples in flight with 2-wave workgroups (a block is one dependent chain: loads -> S -> softmax -> O -> store).
 template <int KB, int NW = 4>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 2 ? 3 : 2))) void attention_kernel(const __bf16* qkv, const int32_t* mask, __bf16* ctx, int L,
-                                                        int heads, float scale_log2e, const int32_t* cu, float* lse) {
+                                                        int heads, float scale_log2e, const int32_t* cu, float* lse, int nqb) {
   __shared__ __attribute__((aligned(16))) char ks[KB * 128];
   __shared__ __attribute__((aligned(16))) char vs[KB * 128];
   __shared__ __attribute__((aligned(16))) float kbias[KB];
 
-  const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  // 1-D grid of (query block, head, sample), query block fastest, in XCD-contiguous order: at L = 512 the four query blocks of a
+  // (sample, head) each walk the same 128 KB of K / V -- dealt round-robin over the XCDs they fetched it four times over the
+  // fabric (1.07 GB per launch at B = 128: the launch ran at the fabric's rate, not the matrix pipes')
+  const int lid = xcd_contiguous_id((int)blockIdx.x, (int)gridDim.x);
+  const int qb = lid % nqb, h = (lid / nqb) % heads, b = lid / (nqb * heads);
   const int H = heads * 64, ld = 3 * H;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, fr = lane & 15, g = lane >> 4;
   size_t tok0 = (size_t)b * L;
@@ -72,26 +77,44 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 2
     for (int qt = 0; qt < 2; ++qt) o[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
 
-  for (int kb0 = 0; kb0 < L; kb0 += KB) {
-    __syncthreads();  // previous block's LDS reads are done
-    // ---- stage K and V tiles (row-major 128-B rows, swizzled 16-B chunks) and the key bias
+  // K / V blocks travel HBM -> registers -> LDS.  With several blocks to walk (the 4-wave form: L > 64) the loads of block k+1
+  // are issued right after block k has been written to LDS and stay in flight under block k's S^T / softmax / PV work (the
+  // issue-early / write-late split: their latency was exposed in front of every block before); one register set, +16 VGPRs.
+  constexpr int NPC = KB * 8 / (NW * 64);       // 16-B pieces per thread per matrix
+  constexpr bool PREFETCH = NW == 4;
+  bf16x8 kreg[NPC], vreg[NPC];
+  float breg = -INFINITY;
+  auto load_block = [&](int kb0) {
 #pragma unroll
-    for (int it = 0; it < KB * 8 / (NW * 64); ++it) {
+    for (int it = 0; it < NPC; ++it) {
       const int idx = tid + NW * 64 * it, key = idx >> 3, c = idx & 7;
       const int kr = (kb0 + key) < L ? (kb0 + key) : L - 1;
       const __bf16* src = qkv + (tok0 + kr) * ld + H + h * 64 + c * 8;
-      const bf16x8 kv = *reinterpret_cast<const bf16x8*>(src);
-      const bf16x8 vv = *reinterpret_cast<const bf16x8*>(src + H);
-      *reinterpret_cast<bf16x8*>(ks + key * 128 + ((c ^ ((key >> 1) & 7)) << 4)) = kv;
-      *reinterpret_cast<bf16x8*>(vs + key * 128 + ((c ^ (((key >> 1) & 3) << 1)) << 4)) = vv;
+      kreg[it] = *reinterpret_cast<const bf16x8*>(src);
+      vreg[it] = *reinterpret_cast<const bf16x8*>(src + H);
     }
     if (tid < KB) {
       const int key = kb0 + tid;
-      float bias = -INFINITY;
-      if (key < L) bias = (!mask || mask[tok0 + key] != 0) ? 0.0f : NEG_MASK;
-      kbias[tid] = bias;
+      breg = -INFINITY;
+      if (key < L) breg = (!mask || mask[tok0 + key] != 0) ? 0.0f : NEG_MASK;
     }
+  };
+  if constexpr (PREFETCH) load_block(0);
+  for (int kb0 = 0; kb0 < L; kb0 += KB) {
+    __syncthreads();  // previous block's LDS reads are done
+    // ---- stage K and V tiles (row-major 128-B rows, swizzled 16-B chunks) and the key bias
+    if constexpr (!PREFETCH) load_block(kb0);
+#pragma unroll
+    for (int it = 0; it < NPC; ++it) {
+      const int idx = tid + NW * 64 * it, key = idx >> 3, c = idx & 7;
+      *reinterpret_cast<bf16x8*>(ks + key * 128 + ((c ^ ((key >> 1) & 7)) << 4)) = kreg[it];
+      *reinterpret_cast<bf16x8*>(vs + key * 128 + ((c ^ (((key >> 1) & 3) << 1)) << 4)) = vreg[it];
+    }
+    if (tid < KB) kbias[tid] = breg;
     __syncthreads();
+    if constexpr (PREFETCH) {
+      if (kb0 + KB < L) load_block(kb0 + KB);
+    }
 
     // ---- S^T = K Q^T : 8 key tiles x 2 query tiles
     constexpr int KT = KB / 16;
@@ -109,38 +132,17 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 2
         for (int qt = 0; qt < 2; ++qt) s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][kk], s[kt][qt], 0, 0, 0);
       }
 
-    // ---- online softmax (scores kept in the log2 domain: exp(x) = exp2(x * log2 e))
+    // ---- online softmax (scores kept in the log2 domain: exp(x) = exp2(x * log2 e)); attn_softmax.hpp
+    bool any_masked = __any(kbias[lane] != 0.0f);            // (the block's key-bias words, 64 per pass; wave-uniform)
+    if constexpr (KB == 128) any_masked = any_masked || __any(kbias[64 + lane] != 0.0f);
     bf16x8 pf[KT / 2][2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-      float mx = -INFINITY;
+      const float alpha = online_softmax_block<KT>(s, qt, kbias, any_masked, g, scale_log2e, m_run[qt], l_run[qt], pf);
+      if (!__all(alpha == 1.0f)) {       // (the running maximum rarely moves after the first blocks: skip the rescale then)
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt) {
-        const f32x4 kbv = *reinterpret_cast<const f32x4*>(kbias + kt * 16 + 4 * g);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = (kbv[r] == 0.0f) ? s[kt][qt][r] * scale_log2e : kbv[r];
-          s[kt][qt][r] = v;
-          mx = fmaxf(mx, v);
-        }
+        for (int dt = 0; dt < 4; ++dt) o[dt][qt] *= alpha;
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run[qt], mx);       // finite: every block holds a key < L
-      const float alpha = exp2f(m_run[qt] - m_new);    // first block: exp2(-inf) = 0
-      float lsum = 0.0f;
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = exp2f(s[kt][qt][r] - m_new);
-          lsum += p;
-          pf[kt >> 1][qt][(kt & 1) * 4 + r] = (__bf16)p;
-        }
-      l_run[qt] = __builtin_fmaf(l_run[qt], alpha, lsum);
-      m_run[qt] = m_new;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) o[dt][qt] *= alpha;
     }
 
     // ---- O^T += V^T P^T : contraction over the block's 128 keys in 4 steps of 32
@@ -201,14 +203,14 @@ extern "C" int ufnd_attention_bf16_lse(const void* qkv, const int32_t* key_mask,
   UFND_REQUIRE(qkv && ctx, "attention: null operand");
   UFND_REQUIRE(B >= 1 && L >= 1 && L <= 4096 && heads >= 1 && heads <= 64, "attention: B=%d L=%d heads=%d", B, L, heads);
   UFND_REQUIRE(ufnd_aligned(qkv, 16) && ufnd_aligned(ctx, 16), "attention: 16-B alignment required");
-  UFND_REQUIRE(B <= 65535, "attention: B too large for grid.z");
+  UFND_REQUIRE((long long)B * heads * ufnd_cdiv(L, QB) < (1ll << 31), "attention: grid too large");
   const float scale_log2e = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) * log2(e)
   if (L <= 64)
-    hipLaunchKernelGGL((attention_kernel<64, 2>), dim3(1, heads, B), dim3(128), 0, (hipStream_t)stream_,
-                       (const __bf16*)qkv, key_mask, (__bf16*)ctx, L, heads, scale_log2e, (const int32_t*)nullptr, lse);
+    hipLaunchKernelGGL((attention_kernel<64, 2>), dim3(heads * B), dim3(128), 0, (hipStream_t)stream_,
+                       (const __bf16*)qkv, key_mask, (__bf16*)ctx, L, heads, scale_log2e, (const int32_t*)nullptr, lse, 1);
   else
-    hipLaunchKernelGGL((attention_kernel<64, 4>), dim3(ufnd_cdiv(L, QB), heads, B), dim3(256), 0, (hipStream_t)stream_,
-                       (const __bf16*)qkv, key_mask, (__bf16*)ctx, L, heads, scale_log2e, (const int32_t*)nullptr, lse);
+    hipLaunchKernelGGL((attention_kernel<64, 4>), dim3(ufnd_cdiv(L, QB) * heads * B), dim3(256), 0, (hipStream_t)stream_,
+                       (const __bf16*)qkv, key_mask, (__bf16*)ctx, L, heads, scale_log2e, (const int32_t*)nullptr, lse, ufnd_cdiv(L, QB));
   UFND_CHECK_LAUNCH();
   return UFND_OK;
 }
@@ -220,8 +222,9 @@ extern "C" int ufnd_attention_bf16_varlen(const void* qkv, const int32_t* cu_seq
                B, max_len, heads);
   UFND_REQUIRE(ufnd_aligned(qkv, 16) && ufnd_aligned(ctx, 16), "attention_varlen: 16-B alignment required");
   const float scale_log2e = 0.125f * 1.44269504088896340736f;
-  hipLaunchKernelGGL((attention_kernel<64, 4>), dim3(ufnd_cdiv(max_len, QB), heads, B), dim3(256), 0, (hipStream_t)stream_,
-                     (const __bf16*)qkv, (const int32_t*)nullptr, (__bf16*)ctx, max_len, heads, scale_log2e, cu_seqlens, (float*)nullptr);
+  hipLaunchKernelGGL((attention_kernel<64, 4>), dim3(ufnd_cdiv(max_len, QB) * heads * B), dim3(256), 0, (hipStream_t)stream_,
+                     (const __bf16*)qkv, (const int32_t*)nullptr, (__bf16*)ctx, max_len, heads, scale_log2e, cu_seqlens, (float*)nullptr,
+                     ufnd_cdiv(max_len, QB));
   UFND_CHECK_LAUNCH();
   return UFND_OK;
 }

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const __bf16* dctx, con
 
 template <int PASS>
 __global__ __launch_bounds__(256) void attention_bwd_kernel(const __bf16* qkv, const __bf16* dctx, const float* lse, const float* delta,
-                                                            const int32_t* mask, __bf16* dqkv, int L, int heads, float scale_log2e, float scale) {
+                                                            const int32_t* mask, __bf16* dqkv, int L, int heads, float scale_log2e, float scale, int nob) {
   // images of the walked side's current 64-row block
   __shared__ __attribute__((aligned(16))) char imgA[64 * 128];      // pass 1: K (form 1)      pass 2: Q  (form 1)
   __shared__ __attribute__((aligned(16))) char imgB[64 * 128];      // pass 1: V (form 1)      pass 2: dO (form 1)
@@ -86,7 +86,9 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const __bf16* qkv, c
   __shared__ __attribute__((aligned(16))) float w0[64];             // pass 1: key bias         pass 2: lse of the block's queries
   __shared__ __attribute__((aligned(16))) float w1[64];             //                          pass 2: delta of the block's queries
 
-  const int ob = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  // (owned block, head, sample), owned block fastest, XCD-contiguous: the blocks of one (sample, head) walk the same rows
+  const int lid = xcd_contiguous_id((int)blockIdx.x, (int)gridDim.x);
+  const int ob = lid % nob, h = (lid / nob) % heads, b = lid / (nob * heads);
   const int H = heads * 64, ld = 3 * H;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, fr = lane & 15, g = lane >> 4;
   const size_t tok0 = (size_t)b * L;
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const __bf16* qkv, c
             ls = wv0[r];
             dl = wv1[r];
           }
-          const float p = exp2f(sc2 - ls);
+          const float p = fast_exp2(sc2 - ls);
           const float dsv = p * (dp[rt][t][r] - dl) * scale;
           pf[rt >> 1][t][(rt & 1) * 4 + r] = (__bf16)p;
           dsf[rt >> 1][t][(rt & 1) * 4 + r] = (__bf16)dsv;
@@ -254,12 +256,14 @@ extern "C" int ufnd_attention_bf16_bwd(const void* qkv, const void* ctx, const v
   const int tokens = B * L;
   hipLaunchKernelGGL(attn_delta_kernel, dim3(ufnd_cdiv(tokens, 4)), dim3(256), 0, stream, (const __bf16*)dctx, (const __bf16*)ctx, workspace, tokens, heads);
   UFND_CHECK_LAUNCH();
-  const dim3 grid(ufnd_cdiv(L, 128), heads, B);
+  const int nob = ufnd_cdiv(L, 128);
+  UFND_REQUIRE((long long)nob * heads * B < (1ll << 31), "attention_bwd: grid too large");
+  const dim3 grid(nob * heads * B);
   hipLaunchKernelGGL(attention_bwd_kernel<1>, grid, dim3(256), 0, stream, (const __bf16*)qkv, (const __bf16*)dctx, lse, (const float*)workspace, key_mask,
-                     (__bf16*)dqkv, L, heads, scale_log2e, scale);
+                     (__bf16*)dqkv, L, heads, scale_log2e, scale, nob);
   UFND_CHECK_LAUNCH();
   hipLaunchKernelGGL(attention_bwd_kernel<2>, grid, dim3(256), 0, stream, (const __bf16*)qkv, (const __bf16*)dctx, lse, (const float*)workspace, key_mask,
-                     (__bf16*)dqkv, L, heads, scale_log2e, scale);
+                     (__bf16*)dqkv, L, heads, scale_log2e, scale, nob);
   UFND_CHECK_LAUNCH();
   return UFND_OK;
 }

@@ -47,6 +47,19 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return cdf + x * pdf;
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// XCD-aware block order (bijective): hardware block id n lands on XCD n % 8 (observed round-robin placement: speed only, never
+// correctness); the logical id returned gives every XCD a CONTIGUOUS range of the grid, so that workgroups with neighbouring
+// logical ids -- the query blocks of one (sample, head), which walk the same K / V rows -- share one XCD's L2 instead of fetching
+// those rows through up to eight of them.
+__device__ __forceinline__ int xcd_contiguous_id(int n, int total) {
+  const int q = total >> 3, r = total & 7, xcd = n & 7, idx = n >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// 2^x as ONE v_exp_f32 (exp2f wraps it in five instructions of denormal-range scaling: compare, select, add, select, ldexp).  The
+// attention kernels call it with x <= 0 on softmax scores: the same bits as exp2f down to 2^-126, zero below (a probability of
+// 1e-38 is zero after the bf16 rounding that follows anyway); a 64-key block needs 32 of them per lane.
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float quick_gelu_grad_f(float x) {      // d/dx [x sigmoid(1.702 x)]
   const float s = 1.0f / (1.0f + __expf(-1.702f * x));
   return s * (1.0f + 1.702f * x * (1.0f - s));

@@ -19,6 +19,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "attn_softmax.hpp"
 
 // No implicit contraction in this file: the epilogues spell every fused multiply-add out (fmaf), so that
 // all tile shapes emit the same floating-point operation sequence (rows are batch-invariant, bit for bit).
@@ -718,37 +719,15 @@ void gemm_bf16_kernel(const GemmArgs a) {
 #pragma unroll
           for (int qt = 0; qt < 2; ++qt) sc[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][kk], sc[kt][qt], 0, 0, 0);
         }
+      const bool any_masked = __any(kbias[kb0 + lane] != 0.0f);      // (64 bias words of this key block: one per lane; wave-uniform)
       bf16x8 pf[KT / 2][2];
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
-        float mx = -INFINITY;
+        const float alpha = online_softmax_block<KT>(sc, qt, kbias + kb0, any_masked, g4, a.att_scale_log2e, m_run[qt], l_run[qt], pf);
+        if (!__all(alpha == 1.0f)) {
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-          const f32x4 kbv = *reinterpret_cast<const f32x4*>(kbias + kb0 + kt * 16 + 4 * g4);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float v = (kbv[r] == 0.0f) ? sc[kt][qt][r] * a.att_scale_log2e : kbv[r];
-            sc[kt][qt][r] = v;
-            mx = fmaxf(mx, v);
-          }
+          for (int dt = 0; dt < 4; ++dt) o[dt][qt] *= alpha;
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run[qt], mx);
-        const float alpha = exp2f(m_run[qt] - m_new);
-        float lsum = 0.0f;
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float pv = exp2f(sc[kt][qt][r] - m_new);
-            lsum += pv;
-            pf[kt >> 1][qt][(kt & 1) * 4 + r] = (__bf16)pv;
-          }
-        l_run[qt] = __builtin_fmaf(l_run[qt], alpha, lsum);
-        m_run[qt] = m_new;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt][qt] *= alpha;
       }
 #pragma unroll
       for (int ksd = 0; ksd < KT / 2; ++ksd) {
