@@ -22,9 +22,17 @@ inline size_t al64(size_t n) { return (n + 63) & ~(size_t)63; }
 // ---------------------------------------------------------------- workspaces
 struct FusionWs {
   float *cat, *qkv, *evid, *gate, *s, *part1, *z1, *h1, *z2;
-  float *dz2, *dz1, *dcatp, *dtavu, *dg, *dqkv, *dout;
+  float *dz2, *dz1, *dcatp, *dtavu, *dg, *dqkv, *dout, *gpart;
   size_t total;
 };
+// Row-sliced parameter reductions (gate_param / node_param): up to PARAM_SLICES_MAX slices of PARAM_SLICE_ROWS rows each, used
+// when the batch has more than PARAM_SLICE_MIN_B rows (at B = 32 the one-pass kernels stay: same bits, no extra launch)
+constexpr int PARAM_SLICE_ROWS = 8, PARAM_SLICES_MAX = 32, PARAM_SLICE_MIN_B = 64;
+inline int param_slices(int B) {
+  if (B <= PARAM_SLICE_MIN_B) return 1;
+  const int s = (B + PARAM_SLICE_ROWS - 1) / PARAM_SLICE_ROWS;
+  return s > PARAM_SLICES_MAX ? PARAM_SLICES_MAX : s;
+}
 FusionWs carve_fusion(const ufnd_dims& d, int B, float* base) {
   const size_t H = d.hidden;
   FusionWs w;
@@ -46,12 +54,13 @@ FusionWs carve_fusion(const ufnd_dims& d, int B, float* base) {
   w.dg = take((size_t)B * H);
   w.dqkv = take((size_t)B * 9 * H);
   w.dout = take((size_t)B * 4);
+  w.gpart = take(param_slices(B) > 1 ? (size_t)param_slices(B) * 3 * (5 * H + 64) : 0);     // gate_param row-slice partials
   w.total = o;
   return w;
 }
 
 struct ClfWs {
-  float *xin, *z3, *h3, *z4, *hh, *alpha, *fs, *df, *dz4, *dz3, *dl;
+  float *xin, *z3, *h3, *z4, *hh, *alpha, *fs, *df, *dz4, *dz3, *dl, *npart;
   int ldx;
   size_t total;
 };
@@ -72,6 +81,8 @@ ClfWs carve_clf(const ufnd_dims& d, int B, float* base) {
   w.dz4 = take((size_t)B * H);
   w.dz3 = take((size_t)B * H);
   w.dl = take((size_t)B * 4);
+  // node_param row-slice partials: per slice [gates TK x H | thresh 64 | bypass 2 x H | bypass bias 64 | leaves trees x 2^depth x 2]
+  w.npart = take(param_slices(B) > 1 ? (size_t)param_slices(B) * ((size_t)(d.trees * d.depth + 2) * H + 128 + (size_t)d.trees * (1 << d.depth) * 2) : 0);
   w.total = o;
   return w;
 }
@@ -312,16 +323,20 @@ __global__ __launch_bounds__(256) void coattn_pairs_bwd_kernel(const float* dcat
   }
 }
 
-// evidence_proj parameter gradients: one block per co-attention block, thread j = hidden unit
-__global__ void gate_param_kernel(const float* evid, const float* dout, int B, int H, EvPtrs p, EvGrads g) {
+// evidence_proj parameter gradients: one block per co-attention block, thread j = hidden unit.  part == NULL: the whole batch in one
+// pass (gridDim.y = 1).  part != NULL (larger batches): block (b, s) sums rows [s R, (s + 1) R) into part[s][b][5 H + 64] =
+// [dw0 (H x 3) | db0 (H) | dw2 (H) | db2]; gate_param_finish_kernel adds the slices in ascending order.
+__global__ void gate_param_kernel(const float* evid, const float* dout, int B, int H, EvPtrs p, EvGrads g, float* part, int R) {
   const int b = blockIdx.x;
+  const int r0 = part ? blockIdx.y * R : 0, r1 = part ? (r0 + R < B ? r0 + R : B) : B;
+  float* pb = part ? part + ((size_t)blockIdx.y * 3 + b) * (5 * H + 64) : nullptr;
   float db2 = 0.0f;
   for (int jj = threadIdx.x; jj < H; jj += blockDim.x) {
     const float w00 = p.w0[b][jj * 3], w01 = p.w0[b][jj * 3 + 1], w02 = p.w0[b][jj * 3 + 2], b0 = p.b0[b][jj],
                 w2 = p.w2[b][jj];
     float dw0[3] = {0, 0, 0}, db0 = 0, dw2 = 0;
 #pragma unroll 8
-    for (int r = 0; r < B; ++r) {
+    for (int r = r0; r < r1; ++r) {
       const f32x4 ev = ld4(evid + (size_t)r * 4);
       float e[3];
       if (b == 0) { e[0] = ev[0]; e[1] = ev[1]; e[2] = 0.f; }
@@ -334,14 +349,32 @@ __global__ void gate_param_kernel(const float* evid, const float* dout, int B, i
       dw0[0] += dpre * e[0]; dw0[1] += dpre * e[1]; dw0[2] += dpre * e[2];
       db0 += dpre;
     }
-    g.w0[b][jj * 3] = dw0[0]; g.w0[b][jj * 3 + 1] = dw0[1]; g.w0[b][jj * 3 + 2] = dw0[2];
-    g.b0[b][jj] = db0;
-    g.w2[b][jj] = dw2;
+    if (pb) {
+      pb[jj * 3] = dw0[0]; pb[jj * 3 + 1] = dw0[1]; pb[jj * 3 + 2] = dw0[2];
+      pb[3 * H + jj] = db0;
+      pb[4 * H + jj] = dw2;
+    } else {
+      g.w0[b][jj * 3] = dw0[0]; g.w0[b][jj * 3 + 1] = dw0[1]; g.w0[b][jj * 3 + 2] = dw0[2];
+      g.b0[b][jj] = db0;
+      g.w2[b][jj] = dw2;
+    }
   }
   if (threadIdx.x == 0) {
 #pragma unroll 8
-    for (int r = 0; r < B; ++r) db2 += dout[(size_t)r * 4 + b];
-    g.b2[b][0] = db2;
+    for (int r = r0; r < r1; ++r) db2 += dout[(size_t)r * 4 + b];
+    if (pb) pb[5 * H] = db2;
+    else g.b2[b][0] = db2;
+  }
+}
+__global__ void gate_param_finish_kernel(const float* part, int S, int H, EvGrads g) {
+  const int b = blockIdx.x, n = 5 * H + 1;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    float s = 0.0f;
+    for (int k = 0; k < S; ++k) s += part[((size_t)k * 3 + b) * (5 * H + 64) + i];
+    if (i < 3 * H) g.w0[b][i] = s;
+    else if (i < 4 * H) g.b0[b][i - 3 * H] = s;
+    else if (i < 5 * H) g.w2[b][i - 4 * H] = s;
+    else g.b2[b][0] = s;
   }
 }
 
@@ -571,9 +604,58 @@ __global__ __launch_bounds__(256) void node_param_kernel(const float* df, const 
                                                          const float* alpha, const float* fs, int B, int H, int trees,
                                                          int depth, float node_p, const ufnd_step_state* st,
                                                          float* g_gates, float* g_thresh, float* g_leaf, float* g_bw,
-                                                         float* g_bb) {
+                                                         float* g_bb, float* part, int R) {
   __shared__ float sh[4];
   const int TK = trees * depth, blk = blockIdx.x;
+  if (part) {
+    // row-sliced form (larger batches): block (blk, s) sums rows [s R, (s + 1) R) of the same products into
+    // part[s] = [da TK x H | dthresh 64 | bypass 2 x H | bypass bias 64 | leaves]; node_param_finish_kernel adds the slices in order
+    const int leaves = 1 << depth, r0 = blockIdx.y * R, r1 = r0 + R < B ? r0 + R : B;
+    float* ps = part + (size_t)blockIdx.y * ((size_t)(TK + 2) * H + 128 + (size_t)trees * leaves * 2);
+    if (blk < TK) {
+      for (int c = threadIdx.x; c < H; c += 256) {
+        float s = 0;
+#pragma unroll 8
+        for (int r = r0; r < r1; ++r) s += df[(size_t)r * 64 + blk] * hh[(size_t)r * H + c];
+        ps[(size_t)blk * H + c] = s;
+      }
+      if (threadIdx.x == 0) {
+        float s = 0;
+        for (int r = r0; r < r1; ++r) s += df[(size_t)r * 64 + blk];
+        ps[(size_t)TK * H + blk] = s;
+      }
+    } else if (blk < TK + 2) {
+      const int c2 = blk - TK;
+      float* pw = ps + (size_t)TK * H + 64 + (size_t)c2 * H;
+      for (int c = threadIdx.x; c < H; c += 256) {
+        float s = 0;
+#pragma unroll 8
+        for (int r = r0; r < r1; ++r) s += dlog[r * 2 + c2] * hh[(size_t)r * H + c];
+        pw[c] = s;
+      }
+      if (threadIdx.x == 0) {
+        float s = 0;
+        for (int r = r0; r < r1; ++r) s += dlog[r * 2 + c2];
+        ps[(size_t)(TK + 2) * H + 64 + c2] = s;
+      }
+    } else {
+      float* pl = ps + (size_t)(TK + 2) * H + 128;
+      for (int idx = threadIdx.x; idx < trees * leaves * 2; idx += 256) {
+        const int c = idx & 1, l = (idx >> 1) % leaves, t = (idx >> 1) / leaves;
+        float s = 0;
+        for (int r = r0; r < r1; ++r) {
+          float prob = 1.0f;
+          for (int k = 0; k < depth; ++k) {
+            const float sk = fs[(size_t)r * 64 + t * depth + k];
+            prob *= ((l >> k) & 1) ? sk : (1.0f - sk);
+          }
+          s += prob * dlog[r * 2 + c] / (float)trees * fs[(size_t)r * 64 + 32 + t * 2 + c];
+        }
+        pl[idx] = s;
+      }
+    }
+    return;
+  }
   if (blk < TK) {
     float da[4] = {0, 0, 0, 0};
     float part = 0;
@@ -633,6 +715,46 @@ __global__ __launch_bounds__(256) void node_param_kernel(const float* df, const 
       }
       g_leaf[idx] = s;
     }
+  }
+}
+
+// adds the row slices of node_param_kernel's partials in ascending order and applies the gate epilogue (alpha (da - alpha . da))
+__global__ __launch_bounds__(256) void node_param_finish_kernel(const float* part, int S, const float* alpha, int H, int trees, int depth,
+                                                                float* g_gates, float* g_thresh, float* g_leaf, float* g_bw, float* g_bb) {
+  __shared__ float sh[4];
+  const int TK = trees * depth, blk = blockIdx.x, leaves = 1 << depth;
+  const size_t PS = (size_t)(TK + 2) * H + 128 + (size_t)trees * leaves * 2;
+  auto total = [&](size_t off) {
+    float s = 0.0f;
+    for (int k = 0; k < S; ++k) s += part[(size_t)k * PS + off];
+    return s;
+  };
+  if (blk < TK) {
+    float da[4] = {0, 0, 0, 0}, dotp = 0;
+#pragma unroll
+    for (int cnt = 0; cnt < 4; ++cnt) {
+      const int c = threadIdx.x + 256 * cnt;
+      if (c < H) {
+        da[cnt] = total((size_t)blk * H + c);
+        dotp += alpha[(size_t)blk * H + c] * da[cnt];
+      }
+    }
+    dotp = wave_sum(dotp);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = dotp;
+    __syncthreads();
+    const float dotv = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+#pragma unroll
+    for (int cnt = 0; cnt < 4; ++cnt) {
+      const int c = threadIdx.x + 256 * cnt;
+      if (c < H) g_gates[(size_t)blk * H + c] = alpha[(size_t)blk * H + c] * (da[cnt] - dotv);
+    }
+    if (threadIdx.x == 0) g_thresh[blk] = -total((size_t)TK * H + blk);
+  } else if (blk < TK + 2) {
+    const int c2 = blk - TK;
+    for (int c = threadIdx.x; c < H; c += 256) g_bw[(size_t)c2 * H + c] = total((size_t)TK * H + 64 + (size_t)c2 * H + c);
+    if (threadIdx.x == 0) g_bb[c2] = total((size_t)(TK + 2) * H + 64 + c2);
+  } else {
+    for (int idx = threadIdx.x; idx < trees * leaves * 2; idx += 256) g_leaf[idx] = total((size_t)(TK + 2) * H + 128 + idx);
   }
 }
 
@@ -906,9 +1028,14 @@ extern "C" int ufnd_fusion_backward_phase(const ufnd_dims* d, const ufnd_fusion_
       eg.w0[b] = g->ev0_w[b]; eg.b0[b] = g->ev0_b[b]; eg.w2[b] = g->ev2_w[b]; eg.b2[b] = g->ev2_b[b];
     }
     fj.fork(2);   // dout, dqkv, dg are ready
-    hipLaunchKernelGGL(gate_param_kernel, dim3(3), dim3(H > 512 ? 512 : H), 0, fj.dw(), (const float*)w.evid,
-                       (const float*)w.dout, B, H, ep, eg);
+    const int S = param_slices(B);
+    hipLaunchKernelGGL(gate_param_kernel, dim3(3, S), dim3(H > 512 ? 512 : H), 0, fj.dw(), (const float*)w.evid,
+                       (const float*)w.dout, B, H, ep, eg, S > 1 ? w.gpart : (float*)nullptr, (B + S - 1) / S);
     UFND_CHECK_LAUNCH();
+    if (S > 1) {
+      hipLaunchKernelGGL(gate_param_finish_kernel, dim3(3), dim3(512), 0, fj.dw(), (const float*)w.gpart, S, H, eg);
+      UFND_CHECK_LAUNCH();
+    }
   }
   // stacked q/k/v: dW, db, and the extra gradient into t, v, a, u (accumulated in place)
   {
@@ -1029,10 +1156,18 @@ extern "C" int ufnd_classifier_backward(const ufnd_dims* d, const ufnd_clf_param
               d->depth, ndrop, drop, state, w.df, w.dz4);
   UFND_CHECK_LAUNCH();
   fj.fork(5);   // df, dz4 are ready
-  hipLaunchKernelGGL(node_param_kernel, dim3(d->trees * d->depth + 3), blk, 0, fj.dw(), (const float*)w.df, d_logits,
-                     (const float*)w.hh, (const float*)w.alpha, (const float*)w.fs, B, H, d->trees, d->depth, ndrop, state,
-                     g->gates, g->thresh, g->leaf, g->bypass_w, g->bypass_b);
-  UFND_CHECK_LAUNCH();
+  {
+    const int S = param_slices(B);
+    hipLaunchKernelGGL(node_param_kernel, dim3(d->trees * d->depth + 3, S), blk, 0, fj.dw(), (const float*)w.df, d_logits,
+                       (const float*)w.hh, (const float*)w.alpha, (const float*)w.fs, B, H, d->trees, d->depth, ndrop, state,
+                       g->gates, g->thresh, g->leaf, g->bypass_w, g->bypass_b, S > 1 ? w.npart : (float*)nullptr, (B + S - 1) / S);
+    UFND_CHECK_LAUNCH();
+    if (S > 1) {
+      hipLaunchKernelGGL(node_param_finish_kernel, dim3(d->trees * d->depth + 3), blk, 0, fj.dw(), (const float*)w.npart, S,
+                         (const float*)w.alpha, H, d->trees, d->depth, g->gates, g->thresh, g->leaf, g->bypass_w, g->bypass_b);
+      UFND_CHECK_LAUNCH();
+    }
+  }
   {  // pre.3: dX -> dz3 (epilogue applies gelu'(z3) * mask)
     NnProb n{w.dz4, p->pre3_w, w.dz3, w.z3, nullptr, B, H, H, H, H, H, H, 0, drop, LAYER_PRE0, H, 1};
     TRY(launch_nn(&n, 1, state, stream));
