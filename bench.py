@@ -55,14 +55,17 @@ def gemm_flops_per_step(B: int) -> tuple[float, int]:
     return text + vis, 12 * 4 + 1 + 12 * 4 + 1
 
 
-def gemm_bytes_per_step(B: int) -> float:
+def gemm_bytes_per_step(B: int, residual_dtype: str = "bf16") -> float:
     """Algorithmic HBM bytes of the same launches: bf16 operands in, bf16 rows out; the two residual GEMMs of a layer
-    also read the fp32 residual stream and write it back (fp32 + bf16 + 8 B of statistics per 32 columns).  The text
-    encoder's fused projection + attention launch (L = 128) reads X and the stacked weight and writes ctx only."""
+    also read the residual stream and write 8 B of row statistics per 32 output columns.  bf16 stream (default): the
+    residual is the bf16 row the previous GEMM wrote (2 B per element) and no fp32 copy exists; fp32 stream: 4 B read +
+    4 B written per element on top.  The text encoder's fused projection + attention launch (L = 128) reads X and the
+    stacked weight and writes ctx only."""
     H, I3 = 768, 3072
+    res = (2.0 if residual_dtype == "bf16" else 8.0) + 0.25
 
     def g(M, N, K, residual):
-        return 2.0 * (M * K + N * K + M * N) + ((8.0 + 0.25) * M * N if residual else 0.0)
+        return 2.0 * (M * K + N * K + M * N) + (res * M * N if residual else 0.0)
 
     def layer(M, fused_attention):
         qkv = 2.0 * (M * H + 3 * H * H + M * H) if fused_attention else g(M, 3 * H, H, False)
@@ -475,7 +478,7 @@ def main():
                          "launches overlap in time on two streams, so this -- not the sum of launch durations -- is what the driver's "
                          "clock can check; nothing else in the step is credited" % n_launch,
                 "traffic": round(traffic) if traffic else None, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": round(gemm_bytes_per_step(G * B) / n_launch),
+                "algorithmic_bytes_per_launch": round(gemm_bytes_per_step(G * B, args.residual_dtype) / n_launch),
                 "launches_per_encoder_pass": n_launch, "optimizer_steps_per_encoder_pass": G, "flops_per_step": flops,
                 "flops_per_launch_avg": flops * G / n_launch,
                 "per_launch": {"how": "HIP events on the launch stream around every launch, sequential instrumented pass after the timed "

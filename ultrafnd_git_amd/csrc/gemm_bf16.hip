@@ -75,6 +75,8 @@ extern "C" int ufnd_gemm_bf16_ln(const void* A, const void* W, const float* bias
   UFND_REQUIRE(ln->a_stats || act == UFND_ACT_NONE, "gemm_bf16_ln: an activation is only fused together with a folded LayerNorm (a_stats)");
   UFND_REQUIRE(ln->width > 0, "gemm_bf16_ln: width (the LayerNorm dimension) must be positive");
   if (ln->a_stats) {
+    UFND_REQUIRE(!residual && !ln->residual_bf16 && !ln->out_stats,
+                 "gemm_bf16_ln: a folded LayerNorm (a_stats) takes no residual and writes no out_stats (that epilogue is compiled without them)");
     UFND_REQUIRE(ln->colsum && ufnd_aligned(ln->colsum, 16) && ufnd_aligned(ln->a_stats, 16), "gemm_bf16_ln: colsum / a_stats alignment");
     UFND_REQUIRE(ln->a_parts >= 2 && ln->a_parts <= 24 && ln->a_parts % 2 == 0, "gemm_bf16_ln: a_parts=%d (even, 2..24)", ln->a_parts);
   }

@@ -507,13 +507,17 @@ void gemm_bf16_kernel(const GemmArgs a) {
   auto epilogue = [&](auto act_, auto mode_) {
     constexpr int ACT = decltype(act_)::value;
     constexpr bool FOLD = LNX && decltype(mode_)::value == 1, RLN = LNX && decltype(mode_)::value == 2;
+    // A folded-LayerNorm call (QKV, FFN1) carries no residual and produces no row statistics (the host entry refuses both):
+    // its epilogue is compiled without them -- with the 128 accumulators of a 256x256 tile alive, the residual registers of
+    // a path never taken were what pushed that kernel into scratch (56 VGPRs spilled, +44 MB read and written per FFN1 launch).
+    constexpr bool RES = !FOLD;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       // the residual rows of this patch are requested first: they land while the patch is staged.  (Requesting them one
       // patch ahead into a second register set changes nothing -- 15.9 us either way for a 256x192 tile at 16,384 rows:
       // that epilogue moves 490 KB per CU on all 256 CUs at once = 7.8 TB/s, it is bound by the fabric, not by latency.)
-      float rr8[NIT][8];
-      if (a.residual) {
+      float rr8[RES ? NIT : 1][8];
+      if constexpr (RES) if (a.residual && !(BWD && a.aux)) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
           const int id = lane + 64 * it;
@@ -539,7 +543,7 @@ void gemm_bf16_kernel(const GemmArgs a) {
           }
         }
       }
-      if constexpr (LNX) {
+      if constexpr (LNX && RES) {
         if (a.residual_b) {
 #pragma unroll
           for (int it = 0; it < NIT; ++it) {
@@ -605,7 +609,7 @@ void gemm_bf16_kernel(const GemmArgs a) {
             }
           }
         }
-        if ((a.residual && !(BWD && a.aux)) || (LNX && a.residual_b)) {
+        if constexpr (RES) if ((a.residual && !(BWD && a.aux)) || (LNX && a.residual_b)) {
           if constexpr (RLN) {      // the residual stream is LayerNorm(residual) * gamma + beta, never materialised
             const f32x2 ms = st_lds[wm * TM + i * MI + rr];
             if constexpr (!FIXCOL) {
@@ -618,7 +622,7 @@ void gemm_bf16_kernel(const GemmArgs a) {
 #pragma unroll
           for (int q = 0; q < 8; ++q) v[q] = __fadd_rn(v[q], rr8[it][q]);
         }
-        if constexpr (LNX) {
+        if constexpr (LNX && RES) {
           if (a.out_stats) {      // partial {sum, sumsq} of the fp32 output row over each aligned 32-column group
             if constexpr (CPR % 4 == 0) {   // (canonical: the partial of columns [32p, 32p+32) never depends on the tile shape)
               float sm = 0.f, sq = 0.f;
