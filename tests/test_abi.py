@@ -84,3 +84,29 @@ def test_diagnostics_are_not_reachable_through_the_product_library():
     n = lib.ufnd_gemm_bf16_tile_count()
     built = [t for t in range(n) if lib.ufnd_gemm_bf16_tile_info(t, None, None, None)]
     assert 4 <= len(built) < n and lib.ufnd_gemm_bf16_tile_info(n, None, None, None) == 0 and lib.ufnd_gemm_bf16_tile_info(-1, None, None, None) == 0
+
+
+def test_no_device_kernel_of_the_product_library_uses_scratch(tmp_path):
+    """Register spills are silent HBM traffic (round 3: 56 spilled VGPRs in the 256x256 LayerNorm-aware GEMM cost 44 MB
+    read + 44 MB written per FFN1 launch and 5 % of the step; only the PMC WRITE_SIZE pass showed it).  The code
+    objects' own metadata says what each kernel reserves: every kernel of the product library must reserve none."""
+    import shutil
+    import subprocess
+    from ultrafnd_git_amd.build import build
+    llvm = Path("/opt/rocm/lib/llvm/bin")
+    if not (llvm / "llvm-objdump").exists() or not (llvm / "llvm-readelf").exists():
+        pytest.skip("ROCm LLVM binutils not present")
+    so = tmp_path / "lib.so"
+    shutil.copy(build(), so)
+    subprocess.run([str(llvm / "llvm-objdump"), "--offloading", so.name], cwd=tmp_path, check=True, capture_output=True)
+    objs = sorted(tmp_path.glob("lib.so.*gfx950"))
+    assert objs, "no gfx950 code object in the library"
+    kernels, bad = 0, []
+    for o in objs:
+        notes = subprocess.run([str(llvm / "llvm-readelf"), "--notes", str(o)], check=True, capture_output=True, text=True).stdout
+        for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", notes):
+            kernels += 1
+            if int(m.group(2)) != 0:
+                bad.append((m.group(1), int(m.group(2))))
+    assert kernels >= 40, kernels
+    assert not bad, bad

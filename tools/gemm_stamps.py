@@ -41,17 +41,21 @@ def main():
         stats = torch.rand(M, 24, 2, device=dev) + 1.0
         vec = torch.rand(max(N, 3072), device=dev)
         res = torch.randn(M, N, device=dev)
+        resb = res.bfloat16()
         of = torch.empty(M, N, device=dev)
         sto = torch.empty(M, 24, 2, device=dev)
         variants = []
         for c, (bm, bn, lay) in TILES.items():
-            if N % bn or (only is not None and c not in only) or c not in (8, 16, 17, 20, 28):      # stamp builds: tiles in use
+            if N % bn or (only is not None and c not in only) or c not in (8, 15, 16, 17, 20, 22, 28):      # stamp builds: tiles in use
                 continue
             variants.append((c, bm, bn, lay, None))
-            if "--ln" in sys.argv and c in (8, 16, 17, 20):
+            if "--ln" in sys.argv and c in (8, 15, 16, 17, 20, 22):
                 variants.append((c, bm, bn, lay + " fold", "fold"))
+                variants.append((c, bm, bn, lay + " fold+gelu", "fold+gelu"))
                 if N // 32 <= 24 and (bn // 2) % 32 == 0:
                     variants.append((c, bm, bn, lay + " rln", "rln"))
+                    variants.append((c, bm, bn, lay + " rlnb", "rlnb"))      # round 3: bf16 residual stream (bf16 in, bf16 + statistics out)
+                    variants.append((c, bm, bn, lay + " resb", "resb"))      # ... without the LayerNorm on the residual (ViT)
                     if "--ablate-rln" in sys.argv:     # the residual epilogue piece by piece
                         for m in ("res0", "res", "res+stats", "rln-nostats"):
                             variants.append((c, bm, bn, lay + " " + m, m))
@@ -64,8 +68,13 @@ def main():
                 ln = L.GemmLn()
                 ln.a_eps = ln.r_eps = 1e-5
                 ln.width = 768
-                if mode == "fold":
+                if mode in ("fold", "fold+gelu"):
                     ln.a_stats, ln.colsum, ln.a_parts = stats.data_ptr(), vec.data_ptr(), 24
+                    ln.tile_cfg = 1 if mode == "fold+gelu" else 0      # (the diagnostics entry reads the activation from this field)
+                elif mode in ("rlnb", "resb"):
+                    if mode == "rlnb":
+                        ln.r_stats, ln.r_gamma, ln.r_beta, ln.r_parts = stats.data_ptr(), vec.data_ptr(), vec.data_ptr(), 24
+                    ln.out_stats, ln.residual_bf16, ln.ldrb = sto.data_ptr(), resb.data_ptr(), N
                 elif mode == "rln":
                     ln.r_stats, ln.r_gamma, ln.r_beta, ln.r_parts, ln.out_stats = stats.data_ptr(), vec.data_ptr(), vec.data_ptr(), 24, sto.data_ptr()
                 elif mode == "rln-nostats":
@@ -77,7 +86,7 @@ def main():
             for it in range(12):
                 dcheck(diag().ufnd_diag_gemm_bf16_stamps(A.data_ptr(), W.data_ptr(), ob.data_ptr(), M, N, K, c, st.data_ptr(),
                                                       ctypes.byref(ln) if ln is not None else None, vec.data_ptr() if mode is not None else None,
-                                                      res.data_ptr() if mode not in (None, "fold") else None, of.data_ptr() if mode not in (None, "fold") else None,
+                                                      res.data_ptr() if mode not in (None, "fold", "fold+gelu", "rlnb", "resb") else None, of.data_ptr() if mode not in (None, "fold", "fold+gelu", "rlnb", "resb") else None,
                                                       L.stream_ptr(A.device)), "stamps")
                 torch.cuda.synchronize()
                 if it >= 4:

@@ -37,7 +37,10 @@ extern "C" int ufnd_diag_gemm_bf16_stamps(const void* A, const void* W, void* ou
     a.a_stats = ln->a_stats; a.colsum = ln->colsum; a.r_stats = ln->r_stats; a.r_gamma = ln->r_gamma; a.r_beta = ln->r_beta;
     a.out_stats = ln->out_stats; a.a_parts = ln->a_parts; a.r_parts = ln->r_parts; a.a_eps = ln->a_eps; a.r_eps = ln->r_eps;
     a.inv_h = 1.0f / (float)ln->width;
-      abl = 5;
+    a.residual_b = (const __bf16*)ln->residual_bf16;      // bf16 residual stream (round 3)
+    a.ldrb = ln->ldrb;
+    if (ln->tile_cfg > 0) a.act = ln->tile_cfg;           // (this entry takes the tile as an argument: the field carries the activation)
+    abl = 5;
   }
   int rc = launch_cfg(tile_cfg, abl, a, (hipStream_t)stream_);
   if (rc != UFND_OK) return rc;
