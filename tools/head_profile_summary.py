@@ -31,8 +31,9 @@ jp = json.loads([l for l in open(prof_json) if l.startswith('{"metric"')][-1])
 ju = json.loads([l for l in open(unprof_json) if l.startswith('{"metric"')][-1])
 shutil.copy(unprof_json, f"profiles/{tag}_unprofiled.json")
 with open(f"profiles/{tag}_summary.md", "w") as f:
-    f.write(f"# {tag}: head-only step (cached features), B = 32\n\nCommand: `rocprofv3 --kernel-trace --stats --output-format csv -d ... -- python3 bench.py "
-            f"--head-only --steps 50 --warmup 10 --repeats 1`; the table covers the last {steps} steps of the trace (steady state).\n\n")
+    B = ju.get("per_gpu_batch", 32)
+    f.write(f"# {tag}: head-only step (cached features), B = {B}\n\nCommand: `rocprofv3 --kernel-trace --stats --output-format csv -d ... -- python3 bench.py "
+            f"--head-only{'' if B == 32 else f' --batch {B}'} --steps {jp['steps']} --warmup {jp['warmup']} --repeats 1`; the table covers the last {steps} steps of the trace (steady state).\n\n")
     f.write(f"Unprofiled, same box: **{ju['value']} samples/s, {ju['ms_per_step']} ms/step**, {ju['roofline']['algorithmic_MB_per_step']} MB algorithmic "
             f"=> **{ju['roofline']['achieved']} GB/s = {ju['roofline']['frac']} of 8 TB/s** (`profiles/{tag}_unprofiled.json`).  Under the profiler: "
             f"{jp['ms_per_step']} ms/step.\n\n")

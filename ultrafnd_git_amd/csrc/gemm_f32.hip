@@ -313,10 +313,15 @@ struct TnArgs {
   int nprob;
 };
 
-template <int VEC>
+// MSPLIT = 0: one wave per tile (4 tiles per workgroup), the whole batch in one wave's chain -- small batches.
+// MSPLIT = 1 (M >= 128): one WORKGROUP per tile, wave w takes the w-th quarter of the batch rows (rounded to 8), the four
+// partial tiles meet in LDS and are added in wave order; wave w stores accumulator registers 4w..4w+3.  At B = 256 the
+// one-wave form is a chain of 8 load-then-MFMA passes with about one wave per SIMD to hide them behind (139 us for the
+// grouped launch, 72 us for the classifier's 272 tiles); this form has 4 x the waves and a quarter of the chain.
+template <int VEC, int MSPLIT = 0>
 __global__ __launch_bounds__(256) void tn_kernel(const TnArgs args) {
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-  const int tile = blockIdx.x * 4 + w;
+  const int tile = MSPLIT ? (int)blockIdx.x : blockIdx.x * 4 + w;
   if (tile >= args.begin[args.nprob]) return;
   int pi = 0;
   for (int q = 1; q < args.nprob; ++q)
@@ -336,8 +341,14 @@ __global__ __launch_bounds__(256) void tn_kernel(const TnArgs args) {
   const float* dycol = P.dY + n0 + j;
   const float* xcol = P.X + (kok ? kcol : 0);
 
+  int m_lo = 0, m_hi = P.M;
+  if constexpr (MSPLIT) {
+    const int per = ((P.M + 3) / 4 + 7) & ~7;
+    m_lo = w * per;
+    m_hi = m_lo + per < P.M ? m_lo + per : P.M;
+  }
   constexpr int U = 4;   // 32 batch rows per pass: every load of the pass is issued before its MFMAs
-  for (int mb = 0; mb < P.M; mb += 8 * U) {
+  for (int mb = m_lo; mb < m_hi; mb += 8 * U) {
     float a[U][4];
     float b[U][4][VEC];
 #pragma unroll
@@ -345,7 +356,7 @@ __global__ __launch_bounds__(256) void tn_kernel(const TnArgs args) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int m = mb + 8 * u + 4 * h + e;
-        const bool ok = m < P.M;
+        const bool ok = m < m_hi;
         a[u][e] = ok ? dycol[(size_t)m * P.lddy] : 0.0f;
         if (ok && kok) {
           const float* src = xcol + (size_t)m * P.ldx;
@@ -371,6 +382,43 @@ __global__ __launch_bounds__(256) void tn_kernel(const TnArgs args) {
       }
   }
 
+  if constexpr (MSPLIT) {
+    __shared__ float red[4][VEC][16][64];
+    __shared__ float dbr[4][64];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[w][v][r][lane] = acc[v][r];
+    dbr[w][lane] = dbsum;
+    __syncthreads();
+    // wave w finalises accumulator registers 4w..4w+3: weight rows n0 + q + 8w + 4h
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float val[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        float t = 0.0f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) t += red[ww][v][4 * w + q][lane];
+        val[v] = t;
+      }
+      if (!kok) continue;
+      float* dst = P.dW + (size_t)(n0 + q + 8 * w + 4 * h) * P.ldw + kcol;
+      if constexpr (VEC == 4) {
+        *reinterpret_cast<f32x4*>(dst) = f32x4{val[0], val[1], val[2], val[3]};
+      } else {
+        *reinterpret_cast<f32x2*>(dst) = f32x2{val[0], val[1]};
+      }
+    }
+    if (strip == 0 && P.db && w == 0) {
+      float t = 0.0f;
+#pragma unroll
+      for (int ww = 0; ww < 4; ++ww) t += dbr[ww][lane];
+      t += __shfl_xor(t, 32, 64);
+      if (h == 0) P.db[n0 + j] = t;
+    }
+    return;
+  } else {
   if (kok) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -388,6 +436,7 @@ __global__ __launch_bounds__(256) void tn_kernel(const TnArgs args) {
   if (strip == 0 && P.db) {
     const float s = dbsum + __shfl_xor(dbsum, 32, 64);
     if (h == 0) P.db[n0 + j] = s;
+  }
   }
 }
 
@@ -497,9 +546,16 @@ int launch_tn(const TnProb* probs, int nprob, hipStream_t stream) {
     total += (a.p[i].N / 32) * ufnd_cdiv(a.p[i].K, 32 * VEC);
   }
   a.begin[nprob] = total;
-  const int blocks = ufnd_cdiv(total, 4);
-  if (vec4) hipLaunchKernelGGL((tn_kernel<4>), dim3(blocks), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL((tn_kernel<2>), dim3(blocks), dim3(256), 0, stream, a);
+  int minM = a.p[0].M;
+  for (int i = 1; i < nprob; ++i) minM = a.p[i].M < minM ? a.p[i].M : minM;
+  if (minM >= 128) {      // batch rows split over the four waves of a workgroup (one workgroup per tile)
+    if (vec4) hipLaunchKernelGGL((tn_kernel<4, 1>), dim3(total), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((tn_kernel<2, 1>), dim3(total), dim3(256), 0, stream, a);
+  } else {
+    const int blocks = ufnd_cdiv(total, 4);
+    if (vec4) hipLaunchKernelGGL((tn_kernel<4>), dim3(blocks), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((tn_kernel<2>), dim3(blocks), dim3(256), 0, stream, a);
+  }
   UFND_CHECK_LAUNCH();
   return UFND_OK;
 }

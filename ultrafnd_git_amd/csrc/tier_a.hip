@@ -366,16 +366,27 @@ __global__ void gate_param_kernel(const float* evid, const float* dout, int B, i
     else g.b2[b][0] = db2;
   }
 }
-__global__ void gate_param_finish_kernel(const float* part, int S, int H, EvGrads g) {
-  const int b = blockIdx.x, n = 5 * H + 1;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    float s = 0.0f;
-    for (int k = 0; k < S; ++k) s += part[((size_t)k * 3 + b) * (5 * H + 64) + i];
-    if (i < 3 * H) g.w0[b][i] = s;
-    else if (i < 4 * H) g.b0[b][i - 3 * H] = s;
-    else if (i < 5 * H) g.w2[b][i - 4 * H] = s;
-    else g.b2[b][0] = s;
+// grid (3, ceil((5 H + 1) / 256)): one element per thread, its S slice loads all in flight (3 workgroups walking 5 H elements x S
+// slices one dependent load at a time took 53 us at B = 256)
+__global__ __launch_bounds__(256) void gate_param_finish_kernel(const float* part, int S, int H, EvGrads g) {
+  const int b = blockIdx.x, n = 5 * H + 1, i = blockIdx.y * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float* src = part + (size_t)b * (5 * H + 64) + i;
+  const size_t stride = (size_t)3 * (5 * H + 64);
+  float s = 0.0f;
+  int k = 0;
+  for (; k + 8 <= S; k += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(k + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];      // ascending slice order, as before
   }
+  for (; k < S; ++k) s += src[(size_t)k * stride];
+  if (i < 3 * H) g.w0[b][i] = s;
+  else if (i < 4 * H) g.b0[b][i - 3 * H] = s;
+  else if (i < 5 * H) g.w2[b][i - 4 * H] = s;
+  else g.b2[b][0] = s;
 }
 
 // dZ = (dY + dlog @ Wc) * gelu'(Z) * dropmask        (entry of the fusion backward)
@@ -724,9 +735,17 @@ __global__ __launch_bounds__(256) void node_param_finish_kernel(const float* par
   __shared__ float sh[4];
   const int TK = trees * depth, blk = blockIdx.x, leaves = 1 << depth;
   const size_t PS = (size_t)(TK + 2) * H + 128 + (size_t)trees * leaves * 2;
-  auto total = [&](size_t off) {
+  auto total = [&](size_t off) {      // ascending slice order; eight slice loads in flight at a time
     float s = 0.0f;
-    for (int k = 0; k < S; ++k) s += part[(size_t)k * PS + off];
+    int k = 0;
+    for (; k + 8 <= S; k += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(k + u) * PS + off];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < S; ++k) s += part[(size_t)k * PS + off];
     return s;
   };
   if (blk < TK) {
@@ -1033,7 +1052,7 @@ extern "C" int ufnd_fusion_backward_phase(const ufnd_dims* d, const ufnd_fusion_
                        (const float*)w.dout, B, H, ep, eg, S > 1 ? w.gpart : (float*)nullptr, (B + S - 1) / S);
     UFND_CHECK_LAUNCH();
     if (S > 1) {
-      hipLaunchKernelGGL(gate_param_finish_kernel, dim3(3), dim3(512), 0, fj.dw(), (const float*)w.gpart, S, H, eg);
+      hipLaunchKernelGGL(gate_param_finish_kernel, dim3(3, ufnd_cdiv(5 * H + 1, 256)), dim3(256), 0, fj.dw(), (const float*)w.gpart, S, H, eg);
       UFND_CHECK_LAUNCH();
     }
   }
