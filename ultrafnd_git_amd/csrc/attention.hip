@@ -116,6 +116,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 2
       if (kb0 + KB < L) load_block(kb0 + KB);
     }
 
+    if constexpr (KB == 64) {
+      if (masked_block_is_noop(kbias, lane, m_run)) continue;      // (attn_softmax.hpp; both barriers of the iteration are behind us / at the loop top)
+    }
     // ---- S^T = K Q^T : 8 key tiles x 2 query tiles
     constexpr int KT = KB / 16;
     f32x4 s[KT][2];

@@ -13,6 +13,16 @@
 #pragma once
 #include "common.hpp"
 
+// A 64-key block whose keys are ALL masked (or beyond L) changes nothing once every query of the wave has seen a live key: its scores
+// are the -3e38 constant (or -inf), so m_new = m_run, alpha = 1, every p = exp2(-3e38 - m_run) = +0 exactly, l and O stay as they are.
+// Wave-uniform test for that case (kb = the block's 64 key-bias words, one per lane): the wave then skips the block's 32 + 32 MFMAs
+// and its softmax -- bit-identical output.  Padding is a suffix of masked keys, so for a batch of ragged lengths this is most of
+// the key blocks of the short samples.  A wave whose queries have seen only masked keys so far (m_run still at the mask constant:
+// HF's uniform-average degenerate case) does NOT skip.
+__device__ __forceinline__ bool masked_block_is_noop(const float* kb, int lane, const float (&m_run)[2]) {
+  return __all(kb[lane] != 0.0f) && __all(m_run[0] > -1.0e30f && m_run[1] > -1.0e30f);
+}
+
 template <int KT>
 __device__ __forceinline__ float online_softmax_block(f32x4 (&s)[KT][2], const int qt, const float* kbias, const bool any_masked, const int g,
                                                       const float scale_log2e, float& m_run, float& l_run, bf16x8 (&pf)[KT / 2][2]) {

@@ -710,6 +710,7 @@ void gemm_bf16_kernel(const GemmArgs a) {
     for (int kb0 = 0; kb0 < BM; kb0 += KB) {
       const char* ks = kimg + kb0 * 128;
       const char* vs = vimg + kb0 * 128;
+      if (masked_block_is_noop(kbias + kb0, lane, m_run)) continue;      // (as attention.hip: bit-identical, see attn_softmax.hpp)
       f32x4 sc[KT][2];
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt)
