@@ -319,6 +319,36 @@ def test_attention(B, Lq, masked):
     assert err <= 3e-2, err          # P and the output are rounded to bf16 (2^-8 relative each); |V| <= ~7
 
 
+def test_attention_masks_that_are_not_a_prefix():
+    """Key blocks that are masked as a whole are passed over once a query has seen a live key (attn_softmax.hpp:
+    masked_block_is_noop) -- a padded suffix is the common case, but the rule has to hold for any mask: a masked FIRST block
+    (left padding: nothing live seen yet, the block must be computed), a masked block between two live ones, live keys only in
+    the last block, a single live key, and no live key at all (HF's uniform average)."""
+    L = _lib()
+    B, Lq, heads, H = 6, 512, 12, 768
+    g = torch.Generator().manual_seed(99)
+    qkv = (torch.randn(B * Lq, 3 * H, generator=g) * 1.5).to(DEV).bfloat16()
+    mask = torch.zeros(B, Lq, dtype=torch.int32)
+    mask[0, 200:] = 1                      # left padding: blocks 0-2 masked as a whole, block 3 partly
+    mask[1, :64] = 1; mask[1, 128:192] = 1; mask[1, 448:] = 1      # masked blocks between live ones
+    mask[2, 500:] = 1                      # live keys in the last block only
+    mask[3, 77] = 1                        # one live key
+    mask[4, :] = 0                         # none
+    mask[5, ::2] = 1                       # no block masked as a whole
+    mask = mask.to(DEV)
+    ctx = torch.empty(B * Lq, H, dtype=torch.bfloat16, device=DEV)
+    L.check(L.lib().ufnd_attention_bf16(qkv.data_ptr(), mask.data_ptr(), ctx.data_ptr(), B, Lq, heads, L.stream_ptr(qkv.device)), "attn")
+    torch.cuda.synchronize()
+    q, k, v = [t.view(B, Lq, heads, 64).transpose(1, 2) for t in qkv.float().split(H, dim=1)]
+    s = (q @ k.transpose(-1, -2)) * 0.125 + (1.0 - mask[:, None, None, :].float()) * torch.finfo(torch.float32).min
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, Lq, H)
+    got = ctx.float().view(B, Lq, H)
+    assert torch.isfinite(got).all()
+    for b in range(B):
+        err = (got[b] - ref[b]).abs().max().item()
+        assert err <= 3e-2, (b, err)
+
+
 @pytest.mark.parametrize("tag", ["bert2_L128", "bert2_L512", "bert2_L40"])
 def test_text_features_match_third_party(tag):
     from oracle import encoders_ref as E

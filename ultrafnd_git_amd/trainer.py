@@ -158,6 +158,7 @@ class ForensicTrainer:
                              "gnn_feat to a head without the GNN slot (the reference silently ignores it; set use_gnn in both places alike)")
         # trainable encoders: their masters join the arena behind the head's, in gradient-ready order (text, then visual)
         self.text_bp = self.vis_bp = None
+        self._enc_side = None      # second stream of the trainable-encoder step (visual encoder beside the text encoder)
         extra = []
         if cfg.train_encoders:
             if not cfg.encode_inline or text_encoder is None or visual_encoder is None or cfg.gnn_in_graph:
@@ -301,16 +302,25 @@ class ForensicTrainer:
     def _train_step_encoders(self, batch: Dict[str, torch.Tensor]) -> dict:
         """train_step with trainable encoders: encoder forwards that keep their activations -> head forward / loss / backward
         -> feature gradients -> encoder backwards (text, then visual; each closes its bucket of the exchange) -> one global-norm
-        clip + AdamW over the joint arena -> the encoders' bf16 operands re-cast from the updated masters.  One stream, no
-        lookahead: every step changes the encoders' weights."""
+        clip + AdamW over the joint arena -> the encoders' bf16 operands re-cast from the updated masters.  No lookahead: every
+        step changes the encoders' weights.  The visual encoder's forward and backward run on a second stream beside the text
+        encoder's (at 32 samples their launches are 150-430 workgroups each: neither chain fills the chip alone); the head sits
+        between the two joins."""
         B = _batch_size(batch)
         b = self.head.bufs(B, True)
         if "dtext" not in b:
             b["dtext"] = torch.empty(B, 768, dtype=torch.float32, device=self.device)
             b["dvis"] = torch.empty(B, 512, dtype=torch.float32, device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        if self._enc_side is None:
+            self._enc_side = torch.cuda.Stream(device=self.device)
+        side = self._enc_side
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            b["visual"].copy_(self.vis_bp.forward_train(batch["frames"]))
         b["text"].copy_(self.text_bp.forward_train(batch["input_ids"], batch["attention_mask"]))
-        b["visual"].copy_(self.vis_bp.forward_train(batch["frames"]))
         b["audio"].copy_(batch["audio_features"])
+        main.wait_stream(side)
         if self.temporal_net is not None:       # (temporal = align(text, visual) is data, as in the reference's cache: no gradient through it)
             self.temporal_net.align_batch(b["text"], b["visual"], out=b["temporal"])
         else:
@@ -325,17 +335,23 @@ class ForensicTrainer:
 
         def tail():
             self.head.feature_grads(b, B, b["dtext"], b["dvis"])
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self.vis_bp.backward(b["dvis"])
             self.text_bp.backward(b["dtext"])
             if self.reducer.active:
-                self.reducer.start(2)
-            self.vis_bp.backward(b["dvis"])
+                self.reducer.start(2)           # (the text encoder's bucket leaves while the visual backward is still running)
+            main.wait_stream(side)
             if self.reducer.active:
                 self.reducer.start(3)
         self.head.fwd_bwd(b, B, tail=tail)
         self.reducer.finish()
         self.optim.clip_and_step()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self.vis_bp.refresh_operands()
         self.text_bp.refresh_operands()
-        self.vis_bp.refresh_operands()
+        main.wait_stream(side)
         self._enc_dirty = True
         return {"loss": self.optim.state.float_view("loss"), "probs": b["probs"], "y": b["label"],
                 "forensic": b["forensic"], "logits": b["logits"]}
