@@ -398,20 +398,41 @@ __global__ __launch_bounds__(256) void ln_fold_guard_kernel(const float* stats, 
   float worst = 0.0f;
   const int nq = parts >> 1, sub = threadIdx.x & 3;
   const long long total = (long long)M * nbuf;
-  for (long long r = (long long)blockIdx.x * 64 + (threadIdx.x >> 2); r < total; r += (long long)gridDim.x * 64) {
-    const int bi = (int)(r / M), row = (int)(r - (long long)bi * M);
-    const f32x4* p = reinterpret_cast<const f32x4*>(stats + bi * buf_stride + (size_t)row * parts * 2);
-    float sm = 0.0f, sq = 0.0f;
-    for (int c = sub; c < nq; c += 4) {
-      const f32x4 v = p[c];
-      sm += v[0] + v[2];
-      sq += v[1] + v[3];
+  // two rows per quad and pass, their (at most 3 + 3: parts <= 24) chunk loads issued together (clamped, masked at use): the
+  // kernel is a stream of 192-B rows and was latency-bound with one load in flight per lane (36 us for 55 MB)
+  const long long step = (long long)gridDim.x * 64;
+  for (long long r = (long long)blockIdx.x * 64 + (threadIdx.x >> 2); r < total; r += 2 * step) {
+    f32x4 v[2][3];
+    bool live[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const long long rk = r + k * step;
+      live[k] = rk < total;
+      const long long rc = live[k] ? rk : r;
+      const int bi = (int)(rc / M), row = (int)(rc - (long long)bi * M);
+      const f32x4* p = reinterpret_cast<const f32x4*>(stats + bi * buf_stride + (size_t)row * parts * 2);
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int c = sub + 4 * u;
+        v[k][u] = p[c < nq ? c : sub];
+      }
     }
-    sm += quad_xor1(sm); sq += quad_xor1(sq);
-    sm += quad_xor2(sm); sq += quad_xor2(sq);
-    const float mean = sm * inv_h;
-    const float var = fmaxf(sq * inv_h - mean * mean, 0.0f);
-    worst = fmaxf(worst, fabsf(mean) * rsqrtf(var + eps));
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      float sm = 0.0f, sq = 0.0f;
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        if (sub + 4 * u < nq) {
+          sm += v[k][u][0] + v[k][u][2];
+          sq += v[k][u][1] + v[k][u][3];
+        }
+      }
+      sm += quad_xor1(sm); sq += quad_xor1(sq);
+      sm += quad_xor2(sm); sq += quad_xor2(sq);
+      const float mean = sm * inv_h;
+      const float var = fmaxf(sq * inv_h - mean * mean, 0.0f);
+      if (live[k]) worst = fmaxf(worst, fabsf(mean) * rsqrtf(var + eps));
+    }
   }
   worst = wave_max(worst);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = worst;
@@ -423,7 +444,7 @@ __global__ __launch_bounds__(256) void ln_fold_guard_kernel(const float* stats, 
 
 extern "C" int ufnd_ln_fold_guard_multi(const float* stats, int M, int parts, int nbuf, size_t buf_stride, int width, float eps, float* guard,
                                         void* stream_) {
-  UFND_REQUIRE(stats && guard && M >= 1 && parts >= 2 && parts % 2 == 0 && nbuf >= 1 && width >= 1 && ufnd_aligned(stats, 16) &&
+  UFND_REQUIRE(stats && guard && M >= 1 && parts >= 2 && parts <= 24 && parts % 2 == 0 && nbuf >= 1 && width >= 1 && ufnd_aligned(stats, 16) &&
                (nbuf == 1 || (buf_stride % 4 == 0 && buf_stride >= (size_t)M * parts * 2)),
                "ln_fold_guard: M=%d parts=%d (even) nbuf=%d stride=%zu", M, parts, nbuf, buf_stride);
   const long long rows = (long long)M * nbuf;
