@@ -12,10 +12,12 @@ DEV = "cuda"
 FEATS = ("text_features", "audio_features", "visual_features", "temporal_features", "gnn_feat")
 
 
-@pytest.mark.parametrize("B", [1, 33, 100, 256])
+@pytest.mark.parametrize("B", [1, 33, 100, 130, 200, 256])
 def test_tier_a_forward_backward_vs_oracle(B):
     """M-tiling paths of the fp32 MFMA kernels: B=1 (one row), 33 / 100 (ragged 32-row tiles), 256
-    (config 3's global batch on one GPU: two row tiles per wave, 8 row groups)."""
+    (config 3's global batch on one GPU: two row tiles per wave, 8 row groups); from 128 rows up the weight-gradient
+    GEMM splits the batch rows over a workgroup's four waves and the gate / NODE parameter reductions are row-sliced:
+    130 and 200 leave the last wave / slice a ragged remainder (10 and 32 rows)."""
     from oracle import tier_a as O
     from ultrafnd_git_amd.classifier import DeepTruthClassifier
     from ultrafnd_git_amd.fusion import CrossModalTransformer
