@@ -12,7 +12,7 @@ stream (small batches of un-normalised features: the norm stays far above max_no
 and reports, every `every` steps, the max-abs difference of the logits on a fixed held-out batch.  hip vs ref64 isolates
 everything that is NOT the norm arithmetic (fp32 summation order inside the kernels, amplified by the training dynamics);
 ref vs ref64 is the effect of the norm arithmetic alone.
-usage: clip_drift.py [steps=200] [B=4] [every=20] [scale=4.0]"""
+usage: clip_drift_study.py [steps=200] [B=4] [every=20] [scale=4.0]"""
 import json
 import sys
 from pathlib import Path

@@ -1,6 +1,6 @@
-"""One-off: measured Tier-B parity numbers (bounds in the tests are set to <= 2x these)."""
+"""Not a test: prints the measured Tier-B parity numbers on a GPU box (`python tests/measure_parity.py`); the bounds in the tests are set to <= 2x these."""
 import json, sys
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parents[1])); sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent))
 import numpy as np, torch
 from helpers import feature_errors, hidden_errors, load_npz
 from oracle import encoders_ref as E
