@@ -113,6 +113,29 @@ def force1(out_dir):
         grp[tag] = (tr.arena.data.clone(), out["logits"].clone(), int(tr.optim.state.read().step))
     res["lookahead_bit_identical"] = bool(torch.equal(grp["exchange"][0], grp["plain"][0]) and torch.equal(grp["exchange"][1], grp["plain"][1])
                                           and grp["exchange"][2] == grp["plain"][2] == 4)
+    # trainable encoders (TrainConfig.train_encoders): four buckets -- the head's two, then the text and the visual encoder's arena
+    # ranges, started as each backward (text on the step's stream, visual on its second stream) completes
+    enc = {}
+    for tag, active in (("exchange", True), ("plain", False)):
+        torch.manual_seed(7)
+        tenc, venc = BertTextEncoder(layers=2, vocab_size=500), ClipVisualEncoder(layers=2)
+        tenc.load_state_dict(wt); venc.load_state_dict(wv)
+        tenc, venc = tenc.to(DEV), venc.to(DEV)
+        cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir=out_dir, batch_size=8, device="cuda:0", use_graph=True, encode_inline=True,
+                          train_encoders=True)
+        tr = ForensicTrainer(cfg, cache=synthetic_cache(32, seed=1), text_encoder=tenc, visual_encoder=venc, force_exchange=active)
+        tr.fusion.train(); tr.clf.train()
+        nb = len(tr.reducer.buckets)
+        for k in range(2):
+            ids, mask = E.synthetic_tokens(80 + k, 8, 32, vocab=500, min_len=8)
+            d = dict_batches(8, 1, 90 + k)[0]
+            d.update({"input_ids": ids.to(DEV), "attention_mask": mask.to(torch.int32).to(DEV), "frames": E.synthetic_frames(95 + k, 8, 1).to(DEV)})
+            out = tr.train_step(d)
+        torch.cuda.synchronize()
+        enc[tag] = (tr.arena.data.clone(), out["logits"].clone(), nb, int(tr.arena.data.numel()))
+    res["train_encoders_bit_identical"] = bool(torch.equal(enc["exchange"][0], enc["plain"][0]) and torch.equal(enc["exchange"][1], enc["plain"][1]))
+    res["train_encoders_buckets"] = enc["exchange"][2]
+    res["train_encoders_arena"] = enc["exchange"][3]
     res["backend"] = dist.get_backend()
     print(json.dumps(res))
     dist.destroy_process_group()

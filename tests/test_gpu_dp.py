@@ -34,6 +34,8 @@ def test_forced_rccl_exchange_on_one_rank_changes_no_bit(launch_job, tmp_path):
     res = _run(launch_job, 1, "force1", tmp_path, {})
     assert res["backend"] == "nccl" and res["steps"] == 3
     assert res["plain_steps_bit_identical"] and res["pipelined_bit_identical"] and res["lookahead_bit_identical"], res
+    # trainable encoders: four buckets (head x 2, text encoder, visual encoder) over the joint arena, two steps
+    assert res["train_encoders_bit_identical"] and res["train_encoders_buckets"] == 4 and res["train_encoders_arena"] > 20_000_000, res
 
 
 def test_two_ranks_on_one_gpu_equal_the_full_batch_step(launch_job, tmp_path):
