@@ -49,7 +49,7 @@ with open(out, "w") as fo:
             tc += busy / util * n
     fo.write(f"\nAll `gemm_bf16_kernel` launches, launch-weighted: MFMA utilisation **{tb / tc:.3f}** of the matrix pipes' cycles while a GEMM is running "
              "(counters serialise the streams: each launch has the chip to itself here).\n")
-    fo.write("\nThe K loop itself issues MFMAs on 73-80 % of its cycles (in-kernel stamps, profiles/r01_gemm_stamps*.txt); the launch-level figure is lower "
-             "because prologue (first operands landing), epilogue (fp32 residual + bf16 + statistics) and the 192-of-256-CU tile counts of the N = 768 / 2304 "
-             "shapes are inside the launch duration.\n")
+    fo.write("\nThe K loop itself issues MFMAs on 75-85 % of its cycles (in-kernel stamps: profiles/r03_gemm_stamps_g4.txt, earlier rounds' profiles/r0*_gemm_stamps*.txt); "
+             "the launch-level figure is lower because prologue (first operands landing), epilogue (GELU, or residual + bf16 + statistics) and the tile counts "
+             "that do not fill whole rounds of 256 CUs (the visual encoder's launches) are inside the launch duration.\n")
 print(open(out).read())
