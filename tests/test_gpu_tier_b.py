@@ -521,6 +521,24 @@ def test_fused_qkv_attention_kernel_is_bit_identical_to_gemm_plus_attention(with
     torch.cuda.synchronize()
     assert torch.isfinite(ctx.float()).all()
     assert torch.equal(ctx, ctx_ref), (ctx.float() - ctx_ref.float()).abs().max().item()
+    # masks that are not a prefix (the key-block skip of attn_softmax.hpp must hold for any mask): left padding with the whole first
+    # 64-key block masked, a masked second block behind a live first one, one live key in the second block only
+    m2 = torch.ones(B, Lq, dtype=torch.int32)
+    m2[0, :70] = 0
+    m2[1, 64:] = 0
+    m2[2, :] = 0; m2[2, 100] = 1
+    m2[3, ::3] = 0
+    m2 = m2.to(DEV).contiguous()
+    ctx.fill_(float("nan"))
+    L.check(L.lib().ufnd_attention_bf16(qkv.data_ptr(), m2.data_ptr(), ctx_ref.data_ptr(), B, Lq, heads, s), "attention")
+    L.check(L.lib().ufnd_qkv_attention_bf16(xb.data_ptr(), W.data_ptr(), b2.data_ptr(), m2.data_ptr(), ctx.data_ptr(), B, Lq, heads, H, H,
+                                            C.byref(ln) if ln is not None else None, s), "qkv_attention")
+    torch.cuda.synchronize()
+    assert torch.isfinite(ctx.float()).all() and torch.equal(ctx, ctx_ref)
+    qq = qkv.float().view(B, Lq, 3, heads, 64)[:4]
+    sc = torch.einsum("bqhd,bkhd->bhqk", qq[:, :, 0], qq[:, :, 1]) * 0.125 + (1.0 - m2[:4, None, None, :].float()) * torch.finfo(torch.float32).min
+    ref4 = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(sc, -1), qq[:, :, 2]).reshape(4, Lq, H)
+    assert (ctx.float().view(B, Lq, H)[:4] - ref4).abs().max().item() <= 3e-2
     # no mask at all == an all-ones mask
     ctx2 = torch.empty_like(ctx)
     ones = torch.ones_like(mask)
