@@ -28,7 +28,7 @@ extern "C" {
 #define UFND_ERR_INVALID 1 /* bad argument: shape, alignment, null pointer */
 #define UFND_ERR_LAUNCH 2  /* HIP launch error */
 
-#define UFND_ABI_VERSION 3
+#define UFND_ABI_VERSION 4
 
 const char* ufnd_last_error(void);
 int ufnd_abi_version(void);
@@ -283,7 +283,14 @@ typedef struct ufnd_gemm_ln {
    * layer (statistics are still taken from the fp32 sums before rounding). */
   const void* residual_bf16;
   int ldrb;
+  /* fold guard inside the GEMM (ABI v4; optional, used with a_stats): UFND_FOLD_GUARD_SLOTS floats.  Every workgroup of the
+   * launch leaves max(slot, largest |mean| * rstd among the rows it folds) in slot (workgroup id % UFND_FOLD_GUARD_SLOTS) -- the
+   * statistics are in its registers at that point anyway, so the guard costs one atomicMax per workgroup at its very end instead
+   * of a kernel that re-reads every statistics buffer of the pass (ufnd_ln_fold_guard_multi: 55-75 MB per pass).  The largest
+   * ratio any folded row has had since the slots were last zeroed = the maximum over the slots (the caller reduces 4 KB). */
+  float* guard;
 } ufnd_gemm_ln;
+#define UFND_FOLD_GUARD_SLOTS 1024
 int ufnd_gemm_bf16_ln(const void* A, const void* W, const float* bias, const float* residual, void* out_bf16,
                       float* out_f32, int M, int N, int K, int lda, int ldw, int ldr, int ldo, int ldf, int act,
                       const ufnd_gemm_ln* ln, void* stream);

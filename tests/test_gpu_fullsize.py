@@ -199,14 +199,18 @@ def _run_fold(x, gm, bt, Wf, b, act=0):
     st = torch.stack([xs.sum(-1), (xs * xs).sum(-1)], -1).contiguous()
     of = torch.empty(M, N, device=DEV)
     guard = torch.zeros(1, device=DEV)
+    slots = torch.zeros(L.FOLD_GUARD_SLOTS, device=DEV)
     ln = L.GemmLn()
     ln.a_stats, ln.colsum, ln.a_parts, ln.a_eps, ln.r_eps, ln.width = st.data_ptr(), colsum.data_ptr(), 12, 1e-5, 1e-5, K
+    ln.guard = slots.data_ptr()         # the GEMM's own report (ABI v4): the largest ratio among the rows each workgroup folds
     L.check(L.lib().ufnd_ln_fold_guard(st.data_ptr(), M, 12, K, 1e-5, guard.data_ptr(), L.stream_ptr(x.device)), "guard")
     xb = x.bfloat16()
     L.check(L.lib().ufnd_gemm_bf16_ln(xb.data_ptr(), Wp.data_ptr(), bias.data_ptr(), None, None, of.data_ptr(), M, N, K, K, K, 0, 0, N, act,
                                       C.byref(ln), L.stream_ptr(x.device)), "gemm_ln")
     torch.cuda.synchronize()
-    return of, float(guard.cpu())
+    # the stand-alone guard kernel and the folding GEMM look at the same statistics: the same maximum (to rounding of the rsqrt)
+    assert abs(float(slots.max().cpu()) - float(guard.cpu())) <= 1e-4 * max(1.0, float(guard.cpu())), (float(slots.max().cpu()), float(guard.cpu()))
+    return of, float(slots.max().cpu())
 
 
 @pytest.mark.parametrize("ratio", [0.0, 1.0, 10.0, 50.0])

@@ -42,6 +42,7 @@ def main():
         vec = torch.rand(max(N, 3072), device=dev)
         res = torch.randn(M, N, device=dev)
         resb = res.bfloat16()
+        gslots = torch.zeros(L.FOLD_GUARD_SLOTS, device=dev)
         of = torch.empty(M, N, device=dev)
         sto = torch.empty(M, 24, 2, device=dev)
         variants = []
@@ -52,6 +53,7 @@ def main():
             if "--ln" in sys.argv and c in (8, 15, 16, 17, 20, 22):
                 variants.append((c, bm, bn, lay + " fold", "fold"))
                 variants.append((c, bm, bn, lay + " fold+gelu", "fold+gelu"))
+                variants.append((c, bm, bn, lay + " fold+gelu+guard", "fold+gelu+guard"))      # round 3: the fold guard inside the GEMM (ufnd_gemm_ln.guard)
                 if N // 32 <= 24 and (bn // 2) % 32 == 0:
                     variants.append((c, bm, bn, lay + " rln", "rln"))
                     variants.append((c, bm, bn, lay + " rlnb", "rlnb"))      # round 3: bf16 residual stream (bf16 in, bf16 + statistics out)
@@ -68,9 +70,11 @@ def main():
                 ln = L.GemmLn()
                 ln.a_eps = ln.r_eps = 1e-5
                 ln.width = 768
-                if mode in ("fold", "fold+gelu"):
+                if mode in ("fold", "fold+gelu", "fold+gelu+guard"):
                     ln.a_stats, ln.colsum, ln.a_parts = stats.data_ptr(), vec.data_ptr(), 24
-                    ln.tile_cfg = 1 if mode == "fold+gelu" else 0      # (the diagnostics entry reads the activation from this field)
+                    ln.tile_cfg = 0 if mode == "fold" else 1      # (the diagnostics entry reads the activation from this field)
+                    if mode == "fold+gelu+guard":
+                        ln.guard = gslots.data_ptr()
                 elif mode in ("rlnb", "resb"):
                     if mode == "rlnb":
                         ln.r_stats, ln.r_gamma, ln.r_beta, ln.r_parts = stats.data_ptr(), vec.data_ptr(), vec.data_ptr(), 24
@@ -86,7 +90,7 @@ def main():
             for it in range(12):
                 dcheck(diag().ufnd_diag_gemm_bf16_stamps(A.data_ptr(), W.data_ptr(), ob.data_ptr(), M, N, K, c, st.data_ptr(),
                                                       ctypes.byref(ln) if ln is not None else None, vec.data_ptr() if mode is not None else None,
-                                                      res.data_ptr() if mode not in (None, "fold", "fold+gelu", "rlnb", "resb") else None, of.data_ptr() if mode not in (None, "fold", "fold+gelu", "rlnb", "resb") else None,
+                                                      res.data_ptr() if mode not in (None, "fold", "fold+gelu", "fold+gelu+guard", "rlnb", "resb") else None, of.data_ptr() if mode not in (None, "fold", "fold+gelu", "fold+gelu+guard", "rlnb", "resb") else None,
                                                       L.stream_ptr(A.device)), "stamps")
                 torch.cuda.synchronize()
                 if it >= 4:

@@ -67,7 +67,7 @@ class GemmLn(C.Structure):
     """ufnd_gemm_ln: the LayerNorm extras of ufnd_gemm_bf16_ln."""
     _fields_ = [("a_stats", _FP), ("colsum", _FP), ("r_stats", _FP), ("r_gamma", _FP), ("r_beta", _FP), ("out_stats", _FP),
                 ("a_parts", C.c_int), ("r_parts", C.c_int), ("a_eps", C.c_float), ("r_eps", C.c_float), ("width", C.c_int),
-                ("tile_cfg", C.c_int), ("residual_bf16", _FP), ("ldrb", C.c_int)]
+                ("tile_cfg", C.c_int), ("residual_bf16", _FP), ("ldrb", C.c_int), ("guard", _FP)]
 
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
@@ -77,7 +77,8 @@ class GemmLn(C.Structure):
 
 STEP_STATE_BYTES = C.sizeof(StepState)
 BWD_ALL, BWD_FUSE_MLP, BWD_REST = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
+FOLD_GUARD_SLOTS = 1024      # UFND_FOLD_GUARD_SLOTS
 
 _lib: Optional[C.CDLL] = None
 

@@ -39,6 +39,7 @@ extern "C" int ufnd_diag_gemm_bf16_stamps(const void* A, const void* W, void* ou
     a.inv_h = 1.0f / (float)ln->width;
     a.residual_b = (const __bf16*)ln->residual_bf16;      // bf16 residual stream (round 3)
     a.ldrb = ln->ldrb;
+    a.guard = ln->a_stats ? ln->guard : nullptr;          // fold guard inside the GEMM (ABI v4)
     if (ln->tile_cfg > 0) a.act = ln->tile_cfg;           // (this entry takes the tile as an argument: the field carries the activation)
     abl = 5;
   }
@@ -58,6 +59,7 @@ extern "C" int ufnd_diag_qkv_attention_stamps(const void* X, const void* Wqkv, c
   if (ln && ln->a_stats) {
     a.a_stats = ln->a_stats; a.colsum = ln->colsum; a.a_parts = ln->a_parts; a.a_eps = ln->a_eps;
     a.inv_h = 1.0f / (float)ln->width;
+    a.guard = ln->guard;
   }
   a.att_mask = key_mask;
   a.att_ctx = (__bf16*)ctx;

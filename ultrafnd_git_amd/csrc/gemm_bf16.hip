@@ -97,6 +97,7 @@ extern "C" int ufnd_gemm_bf16_ln(const void* A, const void* W, const float* bias
   a.inv_h = 1.0f / (float)ln->width;
   a.residual_b = (const __bf16*)ln->residual_bf16;
   a.ldrb = ln->ldrb;
+  a.guard = ln->a_stats ? ln->guard : nullptr;
   int rc = launch_cfg(cfg, 4, a, (hipStream_t)stream_);
   if (rc != UFND_OK) return rc;
   UFND_CHECK_LAUNCH();
@@ -120,6 +121,7 @@ extern "C" int ufnd_qkv_attention_bf16(const void* X, const void* Wqkv, const fl
     UFND_REQUIRE(ln->a_parts >= 2 && ln->a_parts <= 24 && ln->a_parts % 2 == 0 && ln->width > 0, "qkv_attention: a_parts=%d width=%d", ln->a_parts, ln->width);
     a.a_stats = ln->a_stats; a.colsum = ln->colsum; a.a_parts = ln->a_parts; a.a_eps = ln->a_eps;
     a.inv_h = 1.0f / (float)ln->width;
+    a.guard = ln->guard;
   }
   a.att_mask = key_mask;
   a.att_ctx = (__bf16*)ctx;

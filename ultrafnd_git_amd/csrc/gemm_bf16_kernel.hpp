@@ -67,6 +67,9 @@ struct GemmArgs {
   size_t slab_stride;        //      products to out_f32 + s * slab_stride (a reduce pass adds the slabs: ufnd_gemm_bf16_wgrad)
   const __bf16* aux;         // act = UFND_ACT_GELU_BWD / UFND_ACT_QUICK_GELU_BWD: out = acc * act'(aux), aux (M, ldaux) = the
   int ldaux;                 //      pre-activations the forward kept (dgrad through an activation, fused)
+  // fold guard (LNX kernels with a_stats): 1,024 floats; every workgroup leaves the largest |mean| * rstd among the rows it
+  // normalises in slot blockIdx.x % 1024 (one atomicMax at its very end: non-negative floats order like ints)
+  float* guard;
 };
 
 __device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst) {
@@ -124,7 +127,7 @@ template <int V> struct IntC { static constexpr int value = V; };
 // (<= 80 KiB) only do so if two workgroups' waves also fit the register file (8-wave blocks: 128 registers per lane)
 constexpr int gemm_waves_per_simd(int BM, int BN, int WM, int WN, int STA, int STB, int MI, int LNX, int ATT) {
   const int ring = (STA * BM + STB * BN) * 128, cbytes = WM * WN * MI * (BN / WN + 4) * 4;
-  const int smem = (ring > cbytes ? ring : cbytes) + (LNX ? BM * 8 : 0);
+  const int smem = (ring > cbytes ? ring : cbytes) + (LNX ? BM * 8 + 64 : 0);
   return (!ATT && smem <= 80 * 1024 ? 2 : 1) * WM * WN / 4;
 }
 template <int BM, int BN, int WM, int WN, int STA, int STB, int MI, int ABL = 0, int DBG = 0, int LNX = 0, int ATT = 0, int BWD = 0>
@@ -156,7 +159,7 @@ void gemm_bf16_kernel(const GemmArgs a) {
   constexpr int ATT_END = ATT ? ATT_OFF + 6 * 16384 + 512 : 0;
   constexpr int STAT_OFF0 = (RING > CBYTES) ? RING : CBYTES;
   constexpr int STAT_OFF = STAT_OFF0 > ATT_END ? STAT_OFF0 : ATT_END;  // LNX: {mean, rstd} per tile row, behind the ring (and the images)
-  constexpr int SMEM = STAT_OFF + (LNX ? BM * 8 : 0);
+  constexpr int SMEM = STAT_OFF + (LNX ? BM * 8 + 64 : 0);      // (+ 16 floats: the waves' guard maxima)
   static_assert(SMEM <= 160 * 1024, "LDS budget");
   static_assert(APIECES % NW == 0 && TM % MI == 0 && TN % MI == 0, "tile split");
   static_assert(STB >= 2 && (STA == STB || STA == STB + 1), "ring depths");
@@ -335,6 +338,10 @@ void gemm_bf16_kernel(const GemmArgs a) {
       const float var = fmaxf(__fmaf_rn(-mean, mean, __fmul_rn(sq, a.inv_h)), 0.f);
       const float rstd = __builtin_amdgcn_rsqf(__fadd_rn(var, a.a_stats ? a.a_eps : a.r_eps));   // v_rsq_f32 (1 ulp, the same instruction in every tile shape)
       if (threadIdx.x % TPR == 0) st_lds[threadIdx.x / TPR] = f32x2{mean, rstd};
+      if (a.guard && a.a_stats) {      // fold guard: the largest |mean| / std among the rows this workgroup folds (reported at the kernel's end)
+        const float worst = wave_max(threadIdx.x % TPR == 0 ? __fmul_rn(fabsf(mean), rstd) : 0.0f);
+        if (lane == 0) reinterpret_cast<float*>(smem + STAT_OFF + BM * 8)[wave] = worst;
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   }
@@ -767,6 +774,15 @@ void gemm_bf16_kernel(const GemmArgs a) {
         bf16x4 ov = {(__bf16)(o[dt][qt][0] * inv), (__bf16)(o[dt][qt][1] * inv), (__bf16)(o[dt][qt][2] * inv), (__bf16)(o[dt][qt][3] * inv)};
         *reinterpret_cast<bf16x4*>(dst + dt * 16) = ov;
       }
+    }
+  }
+  if constexpr (LNX) {
+    if (a.guard && a.a_stats && threadIdx.x == 0) {      // (the waves' maxima were written in front of the K loop's first barrier)
+      const float* gw = reinterpret_cast<const float*>(smem + STAT_OFF + BM * 8);
+      float worst = gw[0];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) worst = fmaxf(worst, gw[w]);
+      atomicMax(reinterpret_cast<int*>(a.guard + (blockIdx.x & 1023)), __float_as_int(worst));
     }
   }
   if constexpr (DBG) {

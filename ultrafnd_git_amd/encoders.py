@@ -137,6 +137,8 @@ class _EncoderBase(nn.Module):
         ln.tile_cfg = self.tiles.get(which, -1)
         if residual_bf16 is not None:
             ln.residual_bf16, ln.ldrb = residual_bf16.data_ptr(), residual_bf16.stride(0)
+        if a_stats is not None:      # fold guard: the launch reports the largest |mean| / std among the rows it folds
+            ln.guard = self._guard_buf(A.device).data_ptr()
         import ctypes
         L.check(L.lib().ufnd_gemm_bf16_ln(A.data_ptr(), W.data_ptr(), L.ptr(bias), L.ptr(residual), L.ptr(out_bf16),
                                           L.ptr(out_f32), M, N, K, A.stride(0), W.stride(0),
@@ -146,27 +148,21 @@ class _EncoderBase(nn.Module):
                                           L.stream_ptr(A.device)), "ufnd_gemm_bf16_ln")
 
     def _guard_buf(self, dev) -> torch.Tensor:
+        """The fold guard's slots (UFND_FOLD_GUARD_SLOTS floats): every folded GEMM launch -- inside captured graphs too -- leaves
+        the largest |mean| / std among the rows it folds in them (one atomicMax per workgroup, ufnd_gemm_ln.guard), so every
+        row of every batch is looked at by the kernel that folds it; the host reads the slots when it chooses to (check_fold)."""
         if self._guard is None or self._guard.device != dev:
-            self._guard = torch.zeros(1, dtype=torch.float32, device=dev)
+            self._guard = torch.zeros(L.FOLD_GUARD_SLOTS, dtype=torch.float32, device=dev)
         return self._guard
-
-    def _guard_pass(self, st: torch.Tensor, M: int) -> None:
-        """The fold guard of a pass: ONE launch over every statistics buffer the pass wrote (st: (nbuf, rows, parts, 2), the
-        first M rows of each are live).  Part of every folded forward -- captured graphs included -- so every row of every
-        batch is looked at; the host reads the flag when it chooses to (check_fold)."""
-        nbuf = st.shape[0] if st.dim() == 4 else 1
-        L.check(L.lib().ufnd_ln_fold_guard_multi(st.data_ptr(), M, st.shape[-2], nbuf, st.stride(0) if st.dim() == 4 else 0, self.hidden,
-                                                 self.eps, self._guard_buf(st.device).data_ptr(), L.stream_ptr(st.device)),
-                "ufnd_ln_fold_guard_multi")
 
     def fold_ratio(self) -> float:
         """Largest |mean| / std over the rows that went through a folded LayerNorm since the last reset (synchronises)."""
-        return 0.0 if self._guard is None else float(self._guard.cpu())
+        return 0.0 if self._guard is None else float(self._guard.max().cpu())
 
     def check_fold(self, reset: bool = True, ratio: Optional[float] = None) -> bool:
         """The fold guard: True (and folding switched off for every later call, buffers rebuilt) when a folded row's
-        |mean| / std exceeded FOLD_GUARD_MAX.  Every folded forward evaluates the guard on the device (one launch at the
-        end of the pass, inside captured graphs too); this reads it: `strict=True` forwards after each batch (which is then
+        |mean| / std exceeded FOLD_GUARD_MAX.  Every folded GEMM evaluates the guard on the device (inside captured graphs
+        too); this reads it: `strict=True` forwards after each batch (which is then
         repeated unfolded), the trainer after every encoder pass through an asynchronous copy (`ratio=` hands that value in,
         so that nothing synchronises)."""
         r = self.fold_ratio() if ratio is None else float(ratio)
@@ -199,6 +195,7 @@ class _EncoderBase(nn.Module):
         if a_stats is not None:
             ln = L.GemmLn()
             ln.a_stats, ln.colsum, ln.a_parts, ln.a_eps, ln.r_eps, ln.width = a_stats.data_ptr(), colsum.data_ptr(), a_stats.shape[1], eps, eps, self.hidden
+            ln.guard = self._guard_buf(A.device).data_ptr()
         L.check(L.lib().ufnd_qkv_attention_bf16(A.data_ptr(), W.data_ptr(), L.ptr(bias), L.ptr(mask_i32), ctx.data_ptr(), B, Lq, heads,
                                                 A.stride(0), W.stride(0), ctypes.byref(ln) if ln is not None else None,
                                                 L.stream_ptr(A.device)), "ufnd_qkv_attention_bf16")
@@ -288,7 +285,7 @@ class BertTextEncoder(_EncoderBase):
             p2 = L.lib().ufnd_gemm_bf16_stat_parts(M, H, self.inter)
             if self.fold_ln and p1 > 0 and p1 == p2 and p1 % 2 == 0:
                 # one statistics buffer per folded LayerNorm of the pass (st[2i]: layer i's attention half, st[2i+1]: its
-                # feed-forward half), so that ONE guard launch at the end of the pass sees every row (_guard_pass)
+                # feed-forward half); every buffer is read by a folded GEMM, which reports its rows' |mean| / std (fold guard)
                 self._bufs[key].update({"y2": torch.empty(M, H, **f32), "y1b": torch.empty(M, H, **bf), "y2b": torch.empty(M, H, **bf),
                                         "st": torch.zeros(2 * self.layers, M, p1, 2, **f32)})
                 self._guard_buf(dev)
@@ -377,7 +374,6 @@ class BertTextEncoder(_EncoderBase):
                           which="ffn2")      # (the last layer's fp32 sums feed the final, materialised LayerNorm)
             prev = ly
         self._ln(y2, H, prev["g2"], prev["b2n"], None, b["xf"], M, H, eps)           # last_hidden_state is materialised once (fp32 only: no GEMM reads it)
-        self._guard_pass(st, M)
 
     @torch.no_grad()
     def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, unpad: bool = False, strict: bool = False) -> torch.Tensor:
@@ -594,8 +590,6 @@ class ClipVisualEncoder(_EncoderBase):
                 stA = st2
             self._ln(b["xf"], T * H, w[V + "post_layernorm.weight"], w[V + "post_layernorm.bias"], b["pooled"], None, N, H, self.eps)
             self._gemm(b["pooled"], p["wproj"], None, out_f32=b["e"])
-            self._guard_pass(b["st0"], M)
-            self._guard_pass(st, M)
             return b["e"], b
         for ly in p["layers"]:
             self._ln(b["xf"], H, ly["g1"], ly["b1"], b["hb"], None, M, H, self.eps)

@@ -14,8 +14,9 @@ buffers (bench.py: four) -- are read in place by a graph captured for exactly th
 alone would be a 19 MB device-to-device copy per step).  Everything else is staged into the encoder's static buffers and
 replayed from ONE graph per shape; `stats` counts both kinds, and a pinned cache that runs full is reported once.
 
-Fold guard.  Every folded encoder pass ends with one guard launch over all of its LayerNorm statistics (encoders.py); after
-every pass the scheduler copies the two guard words to pinned host memory (asynchronously) and looks at the copies that have
+Fold guard.  Every folded GEMM of an encoder pass reports the largest |mean| / std among the rows it folds (ufnd_gemm_ln.guard:
+1,024 slots per encoder, encoders.py); after every pass the scheduler copies both encoders' slots to pinned host memory
+(asynchronously, 4 KB each) and looks at the copies that have
 landed before it enqueues the next pass: a trip switches that encoder to materialised LayerNorms from the next pass on and
 drops its graphs.  Nothing synchronises."""
 from __future__ import annotations
@@ -127,23 +128,23 @@ class EncoderPipeline:
         while self._guard_pending and self._guard_pending[0][0].query():
             _, slot, which = self._guard_pending.pop(0)
             enc = self.text_encoder if which == "text" else self.visual_encoder
-            if enc is not None and enc.fold_ln and enc.check_fold(reset=False, ratio=float(self._guard_host[slot])):      # (the device word is a running max: never reset here)
+            if enc is not None and enc.fold_ln and enc.check_fold(reset=False, ratio=float(self._guard_host[slot].max())):      # (the device slots are running maxima: never reset here)
                 self.stats["fold_trips"] += 1
                 self.drop_graphs(which)
 
     def _guard_record(self, which: str, enc, stream) -> None:
-        """Behind an encoder pass, on its own stream: copy the encoder's guard word to pinned host memory (asynchronously);
+        """Behind an encoder pass, on its own stream: copy the encoder's guard slots (4 KB) to pinned host memory (asynchronously);
         _guard_poll reads the copies that have completed.  (No extra stream: HIP maps streams onto four hardware queues.)"""
         if enc is None or not enc.fold_ln or enc._guard is None:
             return
         if self._guard_host is None:
-            self._guard_host = torch.zeros(32, dtype=torch.float32).pin_memory()
+            self._guard_host = torch.zeros(32, enc._guard.numel(), dtype=torch.float32).pin_memory()
         if len(self._guard_pending) >= 24:          # the ring is nearly full: the host is far ahead of the device
             self._guard_pending[0][0].synchronize()
             self._guard_poll()
         slot = self._guard_ring
         self._guard_ring = (self._guard_ring + 1) % 32
-        self._guard_host[slot:slot + 1].copy_(enc._guard, non_blocking=True)
+        self._guard_host[slot].copy_(enc._guard, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(stream)
         self._guard_pending.append((ev, slot, which))
