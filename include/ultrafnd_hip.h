@@ -374,8 +374,8 @@ int ufnd_field_mean_l2(const float* parts, const int32_t* valid, float* out, int
  * patches (N*(S/P)^2, 3*P*P) bf16 in the conv weight's (c,ky,kx) order. */
 int ufnd_vit_patchify(const float* frames, void* patches_bf16, int N, int image, int patch, void* stream);
 
-/* tokens = pre_layrnorm([class_embedding ; patch_emb] + position_embedding) -> x_f32 (N, P+1, H);
- * optionally also the bf16 rounding (x_bf16) and the rows' {sum, sumsq} as two partials per row
+/* tokens = pre_layrnorm([class_embedding ; patch_emb] + position_embedding) -> x_f32 (N, P+1, H) and / or its
+ * bf16 rounding x_bf16 (at least one of the two; with the bf16 residual stream only x_bf16), and optionally the rows' {sum, sumsq} as two partials per row
  * (stats (N*(P+1), 2, 2): the a_stats operand of ufnd_gemm_bf16_ln for the first layer). */
 int ufnd_vit_assemble(const float* patch_emb, const float* cls, const float* pos, const float* gamma,
                       const float* beta, float* x_f32, void* x_bf16, float* stats, int N, int P, int H, float eps,

@@ -361,7 +361,7 @@ extern "C" int ufnd_vit_patchify(const float* frames, void* patches, int N, int 
 extern "C" int ufnd_vit_assemble(const float* patch_emb, const float* cls, const float* pos, const float* gamma,
                                  const float* beta, float* x_f32, void* x_bf16, float* stats, int N, int P, int H, float eps,
                                  void* stream_) {
-  UFND_REQUIRE(patch_emb && cls && pos && ((gamma && beta) || (!gamma && !beta)) && x_f32 && N >= 1 && P >= 1, "vit_assemble: null argument");
+  UFND_REQUIRE(patch_emb && cls && pos && ((gamma && beta) || (!gamma && !beta)) && (x_f32 || x_bf16) && N >= 1 && P >= 1, "vit_assemble: null argument");
   UFND_REQUIRE(h_ok(H), "vit_assemble: H=%d", H);
   const int M = N * (P + 1);
   UFND_REQUIRE(!stats || ufnd_aligned(stats, 16), "vit_assemble: stats alignment");

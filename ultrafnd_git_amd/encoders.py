@@ -310,8 +310,8 @@ class BertTextEncoder(_EncoderBase):
                                         w["embeddings.position_embeddings.weight"].data_ptr(),
                                         w["embeddings.token_type_embeddings.weight"].data_ptr(),
                                         w["embeddings.LayerNorm.weight"].data_ptr(), w["embeddings.LayerNorm.bias"].data_ptr(),
-                                        b["xb"].data_ptr(), b["xf"].data_ptr(), B, Lq, H, self.vocab, self.eps,
-                                        L.stream_ptr(dev)), "ufnd_bert_embed")
+                                        b["xb"].data_ptr(), None if ("st" in b and self.residual_dtype == "bf16") else b["xf"].data_ptr(),
+                                        B, Lq, H, self.vocab, self.eps, L.stream_ptr(dev)), "ufnd_bert_embed")      # (bf16 stream, folded: nothing reads the fp32 copy)
         fused = (B, Lq, mask) if (self.fuse_qkv_attention and Lq == 128 and self.heads % 2 == 0) else None
         if n_layers is not None:
             p = {"layers": p["layers"][:max(1, int(n_layers))]}
@@ -570,7 +570,8 @@ class ClipVisualEncoder(_EncoderBase):
         L.check(L.lib().ufnd_vit_assemble(b["pe"].data_ptr(), w[V + "embeddings.class_embedding"].data_ptr(),
                                           w[V + "embeddings.position_embedding.weight"].data_ptr(),
                                           w[V + "pre_layrnorm.weight"].data_ptr(), w[V + "pre_layrnorm.bias"].data_ptr(),
-                                          b["xf"].data_ptr(), L.ptr(b["hb"]) if "st0" in b else None, L.ptr(b.get("st0")),
+                                          None if ("st0" in b and self.residual_dtype == "bf16") else b["xf"].data_ptr(),      # (bf16 stream: hb is the stream)
+                                          L.ptr(b["hb"]) if "st0" in b else None, L.ptr(b.get("st0")),
                                           N, self.n_patches, H, self.eps, s), "ufnd_vit_assemble")
         if "st0" in b:
             # pre-LN blocks without LayerNorm kernels: hb is the bf16 rounding of the residual stream xf,
