@@ -182,7 +182,8 @@ class _EncoderBase(nn.Module):
         """LayerNorm(x; gamma, beta) W^T + b  ==  rstd (x W'^T - mean colsum) + b'  with
         W' = bf16(W * gamma), colsum = row sums of the ROUNDED W', b' = b + W beta."""
         Wp = _bf16(W * gamma[None, :])
-        return Wp, Wp.float().sum(1).contiguous(), (b + W @ beta).contiguous()
+        # (W * beta).sum(1), not W @ beta: packing is one-off setup, but it was the only vendor-BLAS call (rocblas gemv) of the tree
+        return Wp, Wp.float().sum(1).contiguous(), (b + (W * beta[None, :]).sum(1)).contiguous()
 
     def _ln(self, x, ldx, gamma, beta, out_bf16, out_f32, M, H, eps):
         L.check(L.lib().ufnd_layernorm(x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), L.ptr(out_bf16),
