@@ -156,12 +156,14 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ------------------------------------------------------------------ counter-based dropout RNG
-// Philox4x32-10 keyed by the run's seed; counter = (element, layer tag, step).  The same
-// (seed, step, layer, element) always yields the same keep/drop decision, so backward
-// regenerates the forward mask instead of storing it.
-__device__ __forceinline__ uint32_t philox_u32(uint64_t seed, uint64_t step, uint32_t layer, uint32_t elem) {
+// Philox4x32-10 keyed by the run's seed; counter = (element / 4, layer tag, step), element e takes output word e % 4.  The same
+// (seed, step, layer, element) always yields the same keep/drop decision, so backward regenerates the forward mask instead of
+// storing it.  One evaluation (10 rounds, ~110 instructions) serves four consecutive elements: the row kernels and GEMM epilogues
+// that own four aligned elements per lane call dropout_mul4 (round 3; until then every element ran its own evaluation and kept one
+// word of four -- in the GEMM epilogues that was the longest piece of straight-line code).
+__device__ __forceinline__ void philox_4x32(uint64_t seed, uint64_t step, uint32_t layer, uint32_t ctr, uint32_t (&out)[4]) {
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-  uint32_t c0 = elem, c1 = layer, c2 = (uint32_t)step, c3 = (uint32_t)(step >> 32);
+  uint32_t c0 = ctr, c1 = layer, c2 = (uint32_t)step, c3 = (uint32_t)(step >> 32);
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
@@ -173,12 +175,25 @@ __device__ __forceinline__ uint32_t philox_u32(uint64_t seed, uint64_t step, uin
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
-  return c0;
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float dropout_keep(uint32_t r, float p) {
+  const float u = (float)(r >> 8) * (1.0f / 16777216.0f);
+  return (u >= p) ? 1.0f / (1.0f - p) : 0.0f;
 }
 // multiplier applied to an activation: 0 (dropped) or 1/(1-p) (kept).  p == 0 -> 1.
 __device__ __forceinline__ float dropout_mul(const ufnd_step_state* st, float p, uint32_t layer, uint32_t elem) {
   if (p <= 0.0f) return 1.0f;
-  const uint32_t r = philox_u32(st->seed, st->step, layer, elem);
-  const float u = (float)(r >> 8) * (1.0f / 16777216.0f);
-  return (u >= p) ? 1.0f / (1.0f - p) : 0.0f;
+  uint32_t w[4];
+  philox_4x32(st->seed, st->step, layer, elem >> 2, w);
+  const uint32_t k = elem & 3u;
+  return dropout_keep(k == 0 ? w[0] : (k == 1 ? w[1] : (k == 2 ? w[2] : w[3])), p);
+}
+// the multipliers of elements elem4 .. elem4 + 3 (elem4 a multiple of 4): one evaluation
+__device__ __forceinline__ void dropout_mul4(const ufnd_step_state* st, float p, uint32_t layer, uint32_t elem4, float (&m)[4]) {
+  if (p <= 0.0f) { m[0] = m[1] = m[2] = m[3] = 1.0f; return; }
+  uint32_t w[4];
+  philox_4x32(st->seed, st->step, layer, elem4 >> 2, w);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) m[q] = dropout_keep(w[q], p);
 }

@@ -166,8 +166,10 @@ __global__ __launch_bounds__(256) void nt_kernel(const NtArgs args) {
       for (int q = 0; q < 4; ++q) v[q] = gelu_f(v[q]);
     }
     if (P.drop_p > 0.0f) {
+      float dm[4];      // (n is a multiple of 4 and N of 32: four aligned elements, one Philox evaluation)
+      dropout_mul4(args.st, P.drop_p, P.drop_layer, (uint32_t)(m * P.N + n), dm);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] *= dropout_mul(args.st, P.drop_p, P.drop_layer, (uint32_t)(m * P.N + n + q));
+      for (int q = 0; q < 4; ++q) v[q] *= dm[q];
     }
     *reinterpret_cast<f32x4*>(P.Y + (size_t)m * P.ldy + n) = v;
   }
@@ -285,12 +287,18 @@ __global__ __launch_bounds__(256) void nn_kernel(const NnArgs args) {
     }
     if (P.actZ) {
       const float* z = P.actZ + (size_t)mrow * P.ldz + kcol;
+      float dm[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+      if constexpr (VEC == 4) {      // four aligned elements (kcol and drop_ld are multiples of 4 in this form): one Philox evaluation
+        if ((P.drop_ld & 3) == 0) dropout_mul4(args.st, P.drop_p, P.drop_layer, (uint32_t)(mrow * P.drop_ld + kcol), dm);
+        else
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        float g = gelu_grad_f(z[v]);
-        if (P.drop_p > 0.0f) g *= dropout_mul(args.st, P.drop_p, P.drop_layer, (uint32_t)(mrow * P.drop_ld + kcol + v));
-        val[v] *= g;
+          for (int v = 0; v < 4; ++v) dm[v] = dropout_mul(args.st, P.drop_p, P.drop_layer, (uint32_t)(mrow * P.drop_ld + kcol + v));
+      } else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) dm[v] = dropout_mul(args.st, P.drop_p, P.drop_layer, (uint32_t)(mrow * P.drop_ld + kcol + v));
       }
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) val[v] *= gelu_grad_f(z[v]) * dm[v];
     }
     if (P.add) {
       const float* ad = P.add + (size_t)mrow * P.ldadd + kcol;

@@ -106,11 +106,13 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* part,
     for (int s = 1; s < nsplit; ++s) v += ld4(part + (size_t)s * M * N + e);
     if (bias) v += ld4(bias + n);
     if (Z) st4(Z + e, v);
+    float dm[4];
+    dropout_mul4(st, drop_p, layer, (uint32_t)e, dm);      // (e is a multiple of 4: one Philox evaluation for the four elements)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       float x = v[q];
       if (act == 1) x = gelu_f(x);
-      x *= dropout_mul(st, drop_p, layer, (uint32_t)(e + q));
+      x *= dm[q];
       v[q] = x;
     }
     st4(Y + e, v);
@@ -522,6 +524,10 @@ __global__ __launch_bounds__(256) void node_head_kernel(const float* hh, const f
   }
   const int leaves = 1 << depth;
   float lg[2] = {0.f, 0.f};
+  // the row's 2 * trees dropout multipliers: lane j evaluates element row * 2 * trees + j (lanes of one aligned group of four repeat
+  // the same Philox evaluation side by side instead of every lane walking all of them one after the other: 2 * trees evaluations
+  // in a row were the longest chain of this kernel)
+  const float my_dm = lane < 2 * trees ? dropout_mul(st, node_p, LAYER_TREE, (uint32_t)(row * 2 * trees + lane)) : 1.0f;
   for (int t = 0; t < trees; ++t) {
     float prob = 1.0f;
     for (int k = 0; k < depth; ++k) {
@@ -533,7 +539,7 @@ __global__ __launch_bounds__(256) void node_head_kernel(const float* hh, const f
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const float tl = wave_sum(prob * lf[c]);
-      const float dm = dropout_mul(st, node_p, LAYER_TREE, (uint32_t)((row * trees + t) * 2 + c));
+      const float dm = __shfl(my_dm, t * 2 + c, 64);
       lg[c] += tl * dm;
       // backward reads the multiplier back instead of re-running Philox per (row, tree, class) -- in node_param's
       // leaf-table block that was 32 rows x 10 Philox rounds per thread, the longest chain of the whole backward
@@ -602,9 +608,10 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(const float* dlog, const 
     const int col = 4 * lane + 256 * i;
     const f32x4 z = ld4(z4 + (size_t)row * H + col);
     f32x4 o;
+    float dm[4];
+    dropout_mul4(st, clf_p, LAYER_PRE3, (uint32_t)(row * H + col), dm);      // (col and H are multiples of 4)
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      o[q] = acc[i][q] * gelu_grad_f(z[q]) * dropout_mul(st, clf_p, LAYER_PRE3, (uint32_t)(row * H + col + q));
+    for (int q = 0; q < 4; ++q) o[q] = acc[i][q] * gelu_grad_f(z[q]) * dm[q];
     st4(dz4 + (size_t)row * H + col, o);
   }
 }
