@@ -749,21 +749,26 @@ __global__ __launch_bounds__(256) void node_param_kernel(const float* df, const 
       g_bb[c2] = s;
     }
   } else {
-    const int leaves = 1 << depth;
-    for (int idx = threadIdx.x; idx < trees * leaves * 2; idx += 256) {
-      const int c = idx & 1, l = (idx >> 1) % leaves, t = (idx >> 1) / leaves;
-      float s = 0;
-#pragma unroll 8
-      for (int r = 0; r < B; ++r) {
-        float prob = 1.0f;
-        for (int k = 0; k < depth; ++k) {
-          const float sk = fs[(size_t)r * 64 + t * depth + k];
-          prob *= ((l >> k) & 1) ? sk : (1.0f - sk);
-        }
-        s += prob * dlog[r * 2 + c] / (float)trees * fs[(size_t)r * 64 + 32 + t * 2 + c];
+    // leaf tables: workgroup (blk - TK - 2) owns eight table entries, 32 lanes each -- lane r adds rows r, r + 32, ... and the 32 lanes
+    // meet in a fixed butterfly.  (One workgroup walking the rows of all 2 * trees * leaves entries, six dependent loads per row and
+    // entry, was the longest chain of the whole launch: 14.8 us at B = 32.)
+    const int leaves = 1 << depth, n_idx = trees * leaves * 2;
+    const int idx = (blk - TK - 2) * 8 + ((int)threadIdx.x >> 5), r0 = threadIdx.x & 31;
+    const bool live = idx < n_idx;
+    const int ii = live ? idx : 0;
+    const int c = ii & 1, l = (ii >> 1) % leaves, t = (ii >> 1) / leaves;
+    float s = 0;
+    for (int r = r0; r < B; r += 32) {
+      float prob = 1.0f;
+      for (int k = 0; k < depth; ++k) {
+        const float sk = fs[(size_t)r * 64 + t * depth + k];
+        prob *= ((l >> k) & 1) ? sk : (1.0f - sk);
       }
-      g_leaf[idx] = s;
+      s += prob * dlog[r * 2 + c] / (float)trees * fs[(size_t)r * 64 + 32 + t * 2 + c];
     }
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);      // (stays inside each aligned group of 32 lanes)
+    if (live && r0 == 0) g_leaf[idx] = s;
   }
 }
 
@@ -1219,7 +1224,9 @@ extern "C" int ufnd_classifier_backward(const ufnd_dims* d, const ufnd_clf_param
   fj.fork(5);   // df, dz4 are ready
   {
     const int S = param_slices(B);
-    hipLaunchKernelGGL(node_param_kernel, dim3(d->trees * d->depth + 3, S), blk, 0, fj.dw(), (const float*)w.df, d_logits,
+    // (one-pass form: the leaf tables take ceil(2 trees leaves / 8) workgroups of their own; row-sliced form: one per slice)
+    const int leaf_blocks = S > 1 ? 1 : ufnd_cdiv(d->trees * (1 << d->depth) * 2, 8);
+    hipLaunchKernelGGL(node_param_kernel, dim3(d->trees * d->depth + 2 + leaf_blocks, S), blk, 0, fj.dw(), (const float*)w.df, d_logits,
                        (const float*)w.hh, (const float*)w.alpha, (const float*)w.fs, B, H, d->trees, d->depth, ndrop, state,
                        g->gates, g->thresh, g->leaf, g->bypass_w, g->bypass_b, S > 1 ? w.npart : (float*)nullptr, (B + S - 1) / S);
     UFND_CHECK_LAUNCH();
