@@ -507,6 +507,10 @@ __global__ __launch_bounds__(256) void clf_prep_kernel(const float* fused, int l
 }
 
 // NODE ensemble + bypass + temperature softmax        deep_truth_classifier.py:54-74,88-90,164-170
+// One WORKGROUP per row (round 3; one wave per row before): its four waves take a quarter of the gates each (one batch of alpha
+// rows in flight, then that wave's reductions), the bypass rows go to waves 0 and 1, the trees are dealt round-robin; the pieces
+// meet in LDS.  Every gate, tree and class is still one wave's arithmetic in the same order, and the trees are added in
+// ascending order at the end: the same bits as the one-wave form, a quarter of its chain.
 template <int NI>
 __global__ __launch_bounds__(256) void node_head_kernel(const float* hh, const float* alpha, const float* thresh,
                                                         const float* leaf, const float* tau, const float* bw,
@@ -514,55 +518,53 @@ __global__ __launch_bounds__(256) void node_head_kernel(const float* hh, const f
                                                         int trees, int depth, float node_p,
                                                         const ufnd_step_state* st, float* fs, float* logits,
                                                         float* probs) {
+  __shared__ float s_lds[32], byp_lds[2], lg_lds[16][2];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + w;
-  if (row >= B) return;
+  const int row = blockIdx.x;                 // (grid = B)
   f32x4 h[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) h[i] = ld4(hh + (size_t)row * H + 4 * lane + 256 * i);
   const int TK = trees * depth;
-  float my_s = 0.0f;
-  // 8 gate vectors per pass: their 8*NI loads are independent and all in flight before the first
-  // wave reduction (a rolled loop pays one L2 round trip per gate: 24 x ~0.7 us)
-  for (int tk0 = 0; tk0 < TK; tk0 += 8) {
+  // gates tk = w, w + 4, ... (at most 8 per wave: TK <= 32): their 8 * NI loads are independent and all in flight before the first
+  // wave reduction
+  {
     float p[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int tk = (tk0 + u < TK) ? tk0 + u : TK - 1;
+      const int tk = (w + 4 * u < TK) ? w + 4 * u : TK - 1;
       float acc = 0;
 #pragma unroll
       for (int i = 0; i < NI; ++i) acc += dot4(h[i], ld4(alpha + (size_t)tk * H + 4 * lane + 256 * i));
       p[u] = acc;
     }
+    float bypass = 0;
+    if (w < 2) {                              // (wave-uniform) bypass row w
+#pragma unroll
+      for (int i = 0; i < NI; ++i) bypass += dot4(h[i], ld4(bw + (size_t)w * H + 4 * lane + 256 * i));
+    }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int tk = tk0 + u;
+      const int tk = w + 4 * u;
       const float f = wave_sum(p[u]);
-      if (tk < TK) {
+      if (tk < TK && lane == 0) {
         const float sv = sigmoid_f(tau[tk / depth] * (f - thresh[tk]));
-        if (lane == tk) my_s = sv;
+        s_lds[tk] = sv;
+        fs[(size_t)row * 64 + tk] = sv;
       }
     }
+    if (w < 2) {
+      const float bsum = wave_sum(bypass) + bb[w];
+      if (lane == 0) byp_lds[w] = bsum;
+    }
   }
-  if (lane < TK) fs[(size_t)row * 64 + lane] = my_s;
-  float byp[2];
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    float p = 0;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) p += dot4(h[i], ld4(bw + (size_t)c * H + 4 * lane + 256 * i));
-    byp[c] = wave_sum(p) + bb[c];
-  }
-  const int leaves = 1 << depth;
-  float lg[2] = {0.f, 0.f};
-  // the row's 2 * trees dropout multipliers: lane j evaluates element row * 2 * trees + j (lanes of one aligned group of four repeat
-  // the same Philox evaluation side by side instead of every lane walking all of them one after the other: 2 * trees evaluations
-  // in a row were the longest chain of this kernel)
+  __syncthreads();
+  // the row's 2 * trees dropout multipliers: lane j evaluates element row * 2 * trees + j (every wave the same values)
   const float my_dm = lane < 2 * trees ? dropout_mul(st, node_p, LAYER_TREE, (uint32_t)(row * 2 * trees + lane)) : 1.0f;
-  for (int t = 0; t < trees; ++t) {
+  const int leaves = 1 << depth;
+  for (int t = w; t < trees; t += 4) {
     float prob = 1.0f;
     for (int k = 0; k < depth; ++k) {
-      const float sk = __shfl(my_s, t * depth + k, 64);
+      const float sk = s_lds[t * depth + k];
       prob *= ((lane >> k) & 1) ? sk : (1.0f - sk);
     }
     if (lane >= leaves) prob = 0.0f;
@@ -571,14 +573,18 @@ __global__ __launch_bounds__(256) void node_head_kernel(const float* hh, const f
     for (int c = 0; c < 2; ++c) {
       const float tl = wave_sum(prob * lf[c]);
       const float dm = __shfl(my_dm, t * 2 + c, 64);
-      lg[c] += tl * dm;
-      // backward reads the multiplier back instead of re-running Philox per (row, tree, class) -- in node_param's
-      // leaf-table block that was 32 rows x 10 Philox rounds per thread, the longest chain of the whole backward
-      if (lane == 0) fs[(size_t)row * 64 + 32 + t * 2 + c] = dm;
+      if (lane == 0) {
+        lg_lds[t][c] = tl * dm;
+        // backward reads the multiplier back instead of re-running Philox per (row, tree, class)
+        fs[(size_t)row * 64 + 32 + t * 2 + c] = dm;
+      }
     }
   }
-  if (lane == 0) {
-    const float l0 = lg[0] / (float)trees + byp[0], l1 = lg[1] / (float)trees + byp[1];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float lg[2] = {0.f, 0.f};
+    for (int t = 0; t < trees; ++t) { lg[0] += lg_lds[t][0]; lg[1] += lg_lds[t][1]; }      // ascending tree order, as the one-wave form added them
+    const float l0 = lg[0] / (float)trees + byp_lds[0], l1 = lg[1] / (float)trees + byp_lds[1];
     logits[row * 2] = l0;
     logits[row * 2 + 1] = l1;
     const float T = fminf(fmaxf(temperature[0], 0.5f), 5.0f);
@@ -1195,7 +1201,7 @@ extern "C" int ufnd_classifier_forward(const ufnd_dims* d, const ufnd_clf_params
     NtProb b{w.h3, p->pre3_w, p->pre3_b, w.hh, w.z4, B, H, H, H, H, H, H, 1, drop, LAYER_PRE3, 1};
     TRY(launch_nt(&b, 1, state, stream));
   }
-  NI_DISPATCH(H, node_head_kernel, rows, blk, stream, (const float*)w.hh, (const float*)w.alpha, (const float*)p->thresh,
+  NI_DISPATCH(H, node_head_kernel, dim3(B), blk, stream, (const float*)w.hh, (const float*)w.alpha, (const float*)p->thresh,
               (const float*)p->leaf, (const float*)p->tau, (const float*)p->bypass_w, (const float*)p->bypass_b,
               (const float*)p->temperature, B, H, d->trees, d->depth, train ? d->node_dropout : 0.0f, state, w.fs, logits,
               probs);
