@@ -596,59 +596,98 @@ __global__ __launch_bounds__(256) void node_head_kernel(const float* hh, const f
 }
 
 // backward through logits = mean_t(drop(probs_t @ leaf_t)) + bypass(h), down to dZ4
+// One WORKGROUP per row (round 3; one wave per row before).  Wave 0: the gates' score gradients df (lanes < trees * depth, each
+// walking its tree's leaves) and the bypass term of dh; waves 1-3: a third of the gates each -- their alpha rows are requested
+// BEFORE the barrier that publishes df, so the loads fly under wave 0's leaf loops -- then d * alpha in ascending gate order.
+// The four partial rows meet in LDS as (P0 + P1) + (P2 + P3); the GELU derivative, the dropout mask and the store follow on
+// H / 4 threads.  (A fixed order, but not the one-wave form's: gradients agree to rounding, not bit for bit.)
 template <int NI>
 __global__ __launch_bounds__(256) void node_bwd_kernel(const float* dlog, const float* fs, const float* alpha,
                                                        const float* leaf, const float* tau, const float* bw,
                                                        const float* z4, int B, int H, int trees, int depth,
                                                        float node_p, float clf_p, const ufnd_step_state* st,
                                                        float* df, float* dz4) {
+  __shared__ float df_lds[32];
+  __shared__ f32x4 part[4][NI][64];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + w;
-  if (row >= B) return;
+  const int row = blockIdx.x;                 // (grid = B)
   const float dl0 = dlog[row * 2], dl1 = dlog[row * 2 + 1];
   const int TK = trees * depth, leaves = 1 << depth;
-  float my_df = 0.0f;
-  if (lane < TK) {
-    const int t = lane / depth, k = lane % depth;
-    const float d0 = dl0 / (float)trees * fs[(size_t)row * 64 + 32 + t * 2];          // cached dropout multipliers (node_head)
-    const float d1 = dl1 / (float)trees * fs[(size_t)row * 64 + 32 + t * 2 + 1];
-    float ds = 0.0f;
-    for (int l = 0; l < leaves; ++l) {
-      float prod = 1.0f;
-      for (int jj = 0; jj < depth; ++jj) {
-        if (jj == k) continue;
-        const float sj = fs[(size_t)row * 64 + t * depth + jj];
-        prod *= ((l >> jj) & 1) ? sj : (1.0f - sj);
-      }
-      const float* lf = leaf + ((size_t)t * leaves + l) * 2;
-      const float dprob = lf[0] * d0 + lf[1] * d1;
-      ds += (((l >> k) & 1) ? dprob : -dprob) * prod;
-    }
-    const float sk = fs[(size_t)row * 64 + lane];
-    my_df = ds * tau[t] * sk * (1.0f - sk);
-    df[(size_t)row * 64 + lane] = my_df;
-  }
+  constexpr int GW = 11;                      // gates per wave of waves 1-3: ceil(32 / 3)
+  f32x4 av[GW][NI];
   f32x4 acc[NI];
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int col = 4 * lane + 256 * i;
-    acc[i] = dl0 * ld4(bw + col) + dl1 * ld4(bw + H + col);
-  }
-#pragma unroll 8
-  for (int tk = 0; tk < TK; ++tk) {
-    const float d = __shfl(my_df, tk, 64);
+  for (int i = 0; i < NI; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (w == 0) {
+    {
+      // lanes tk and tk + 32 share gate tk: the lower half of the wave walks the first half of the tree's leaves, the upper half the
+      // second; the tree's gate scores are loaded once (depth <= 6), not per leaf
+      const int tk = lane & 31, half = lane >> 5;
+      const int tc = tk < TK ? tk : TK - 1;
+      const int t = tc / depth, k = tc % depth;
+      const float d0 = dl0 / (float)trees * fs[(size_t)row * 64 + 32 + t * 2];          // cached dropout multipliers (node_head)
+      const float d1 = dl1 / (float)trees * fs[(size_t)row * 64 + 32 + t * 2 + 1];
+      float sj[6];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) acc[i] += d * ld4(alpha + (size_t)tk * H + 4 * lane + 256 * i);
+      for (int jj = 0; jj < 6; ++jj) sj[jj] = jj < depth ? fs[(size_t)row * 64 + t * depth + jj] : 0.0f;
+      float ds = 0.0f;
+      const int l_lo = half * (leaves >> 1), l_hi = l_lo + (leaves >> 1);      // (depth >= 1: leaves is even)
+      for (int l = l_lo; l < l_hi; ++l) {
+        float prod = 1.0f;
+#pragma unroll
+        for (int jj = 0; jj < 6; ++jj) {
+          if (jj < depth && jj != k) prod *= ((l >> jj) & 1) ? sj[jj] : (1.0f - sj[jj]);
+        }
+        const f32x2 lf = *reinterpret_cast<const f32x2*>(leaf + ((size_t)t * leaves + l) * 2);
+        const float dprob = lf[0] * d0 + lf[1] * d1;
+        ds += (((l >> k) & 1) ? dprob : -dprob) * prod;
+      }
+      ds += __shfl_xor(ds, 32, 64);
+      const float sk = fs[(size_t)row * 64 + tc];
+      const float my_df = ds * tau[t] * sk * (1.0f - sk);
+      if (lane < TK) {
+        df[(size_t)row * 64 + lane] = my_df;
+        df_lds[lane] = my_df;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int col = 4 * lane + 256 * i;
+      acc[i] = dl0 * ld4(bw + col) + dl1 * ld4(bw + H + col);
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < GW; ++u) {
+      const int tk = (w - 1) + 3 * u;
+      const int tc = tk < TK ? tk : TK - 1;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) av[u][i] = ld4(alpha + (size_t)tc * H + 4 * lane + 256 * i);
+    }
+  }
+  __syncthreads();
+  if (w != 0) {
+#pragma unroll
+    for (int u = 0; u < GW; ++u) {
+      const int tk = (w - 1) + 3 * u;
+      if (tk < TK) {                          // (wave-uniform)
+        const float d = df_lds[tk];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) acc[i] += d * av[u][i];
+      }
+    }
   }
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int col = 4 * lane + 256 * i;
+  for (int i = 0; i < NI; ++i) part[w][i][lane] = acc[i];
+  __syncthreads();
+  for (int c4 = threadIdx.x; c4 < H / 4; c4 += 256) {
+    const int i = c4 >> 6, ln = c4 & 63, col = 4 * c4;
+    const f32x4 a = (part[0][i][ln] + part[1][i][ln]) + (part[2][i][ln] + part[3][i][ln]);
     const f32x4 z = ld4(z4 + (size_t)row * H + col);
     f32x4 o;
     float dm[4];
     dropout_mul4(st, clf_p, LAYER_PRE3, (uint32_t)(row * H + col), dm);      // (col and H are multiples of 4)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) o[q] = acc[i][q] * gelu_grad_f(z[q]) * dm[q];
+    for (int q = 0; q < 4; ++q) o[q] = a[q] * gelu_grad_f(z[q]) * dm[q];
     st4(dz4 + (size_t)row * H + col, o);
   }
 }
@@ -1223,7 +1262,7 @@ extern "C" int ufnd_classifier_backward(const ufnd_dims* d, const ufnd_clf_param
   const float drop = train ? d->clf_dropout : 0.0f, ndrop = train ? d->node_dropout : 0.0f;
   const dim3 rows(ufnd_cdiv(B, 4)), blk(256);
 
-  NI_DISPATCH(H, node_bwd_kernel, rows, blk, stream, d_logits, (const float*)w.fs, (const float*)w.alpha,
+  NI_DISPATCH(H, node_bwd_kernel, dim3(B), blk, stream, d_logits, (const float*)w.fs, (const float*)w.alpha,
               (const float*)p->leaf, (const float*)p->tau, (const float*)p->bypass_w, (const float*)w.z4, B, H, d->trees,
               d->depth, ndrop, drop, state, w.df, w.dz4);
   UFND_CHECK_LAUNCH();
