@@ -230,6 +230,115 @@ __global__ __launch_bounds__(256) void coattn_pairs_kernel(float* cat, const flo
   if (lane == 0) st4(s_out + (size_t)row * 4, f32x4{s[0], s[1], s[2], 0.f});
 }
 
+// The same row, ONE WORKGROUP per row (round 3): wave 0 the evidence scalars while waves 1-3 take one co-attention score each; then
+// waves 0-2 one evidence gate each (their parameter loads requested before the barrier); then the 11 pairwise / co-attention slots
+// are dealt over the waves by column chunk and slot group.  Every scalar is still one wave's reduction over the same lanes and
+// every element the same expression: the same bits as coattn_pairs_kernel<NI, 1>, a third of its chain.
+template <int NI>
+__global__ __launch_bounds__(256) void coattn_pairs_wg_kernel(float* cat, const float* qkv, float* gate_io, int B, int H, float* s_out,
+                                                              EvPtrs ev, float* evid, float* forensic) {
+  __shared__ float e_lds[4], g_lds[4], s_lds[4];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x;
+  float* c = cat + (size_t)row * 16 * H;
+  const float* q = qkv + (size_t)row * 9 * H;
+  const int QI[3] = {0, 1, 4}, KI[3] = {2, 5, 7}, VI[3] = {3, 6, 8};
+  const int XS[3] = {0, 0, 2}, YS[3] = {2, 1, 3};
+  // gate parameters of block w (waves 0-2), requested now: 4 NI hidden units per lane
+  float pw0[4 * NI][3], pb0[4 * NI], pw2[4 * NI];
+  if (w < 3) {
+#pragma unroll
+    for (int q4 = 0; q4 < 4 * NI; ++q4) {
+      const int jj = lane + 64 * q4;
+      pw0[q4][0] = ev.w0[w][jj * 3 + 0]; pw0[q4][1] = ev.w0[w][jj * 3 + 1]; pw0[q4][2] = ev.w0[w][jj * 3 + 2];
+      pb0[q4] = ev.b0[w][jj];
+      pw2[q4] = ev.w2[w][jj];
+    }
+  }
+  if (w == 0) {          // evidence scalars (evidence_row's first half)
+    float tt = 0, vv = 0, uu = 0, tv = 0, tu = 0, ta = 0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int col = 4 * lane + 256 * i;
+      const f32x4 t = ld4(c + col), v = ld4(c + 2 * H + col), u = ld4(c + 3 * H + col);
+      tt += dot4(t, t); vv += dot4(v, v); uu += dot4(u, u); tv += dot4(t, v); tu += dot4(t, u);
+      ta += fabsf(t[0]) + fabsf(t[1]) + fabsf(t[2]) + fabsf(t[3]);
+    }
+    tt = wave_sum(tt); vv = wave_sum(vv); uu = wave_sum(uu); tv = wave_sum(tv); tu = wave_sum(tu); ta = wave_sum(ta);
+    const float nt = fmaxf(sqrtf(tt), 1e-12f), nv = fmaxf(sqrtf(vv), 1e-12f), nu = fmaxf(sqrtf(uu), 1e-12f);
+    const float conf = 1.0f - 0.5f * (fminf(fmaxf(tv / (nt * nv), -1.0f), 1.0f) + 1.0f);
+    const float delay = 1.0f - 0.5f * (fminf(fmaxf(tu / (nt * nu), -1.0f), 1.0f) + 1.0f);
+    const float emo = tanhf(ta / (float)H);
+    if (lane == 0) {
+      e_lds[0] = conf; e_lds[1] = emo; e_lds[2] = delay;
+      st4(evid + (size_t)row * 4, f32x4{conf, emo, delay, 0.f});
+      forensic[row] = emo;                // emotion_intensity
+      forensic[B + row] = conf;           // semantic_conflict
+      forensic[2 * B + row] = delay;      // temporal_delay
+    }
+  } else {               // co-attention score of block w - 1
+    const int b = w - 1;
+    float dots = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int col = 4 * lane + 256 * i;
+      dots += dot4(ld4(q + QI[b] * H + col), ld4(q + KI[b] * H + col));
+    }
+    const float inv = 1.0f / sqrtf((float)H);
+    const float sb = sigmoid_f(wave_sum(dots) * inv);
+    if (lane == 0) s_lds[b] = sb;
+  }
+  __syncthreads();
+  if (w < 3) {           // evidence gate of block w (evidence_row's second half)
+    const float conf = e_lds[0], emo = e_lds[1], delay = e_lds[2];
+    const float e0 = w == 0 ? conf : (w == 1 ? emo : delay), e1 = w == 0 ? emo : 0.f, e2 = 0.f;
+    float o = 0.0f;
+#pragma unroll
+    for (int q4 = 0; q4 < 4 * NI; ++q4) {
+      const float pre = pw0[q4][0] * e0 + pw0[q4][1] * e1 + pw0[q4][2] * e2 + pb0[q4];
+      o += pw2[q4] * gelu_f(pre);
+    }
+    const float gb = sigmoid_f(wave_sum(o) + ev.b2[w][0]);
+    if (lane == 0) g_lds[w] = gb;
+  }
+  __syncthreads();
+  const float g3[3] = {g_lds[0], g_lds[1], g_lds[2]}, s3[3] = {s_lds[0], s_lds[1], s_lds[2]};
+  if (threadIdx.x == 0) {
+    st4(gate_io + (size_t)row * 4, f32x4{g3[0], g3[1], g3[2], 0.f});
+    st4(s_out + (size_t)row * 4, f32x4{s3[0], s3[1], s3[2], 0.f});
+  }
+  // slots 4..14: wave w takes column chunk w % NI and slot group w / NI of SG = 4 / NI groups
+  constexpr int SG = 4 / NI;
+  const int i = w % NI, sg = w / NI;
+  auto mine = [&](int slot) { return ((slot - 4) * SG) / 11 == sg; };
+  {
+    const int col = 4 * lane + 256 * i;
+    const f32x4 t = ld4(c + col), a = ld4(c + H + col), v = ld4(c + 2 * H + col), u = ld4(c + 3 * H + col);
+    f32x4 ab;
+    if (mine(4)) st4(c + 4 * H + col, t + a);
+    if (mine(5)) st4(c + 5 * H + col, t * a);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ab[k] = fabsf(t[k] - a[k]);
+    if (mine(6)) st4(c + 6 * H + col, ab);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ab[k] = fabsf(t[k] - v[k]);
+    if (mine(7)) st4(c + 7 * H + col, t + v);
+    if (mine(8)) st4(c + 8 * H + col, t * v);
+    if (mine(9)) st4(c + 9 * H + col, ab);
+    if (mine(10)) st4(c + 10 * H + col, t + u);
+    if (mine(11)) st4(c + 11 * H + col, v + u);
+    const f32x4 xs[4] = {t, a, v, u};
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      if (mine(12 + b)) {
+        const f32x4 val = ld4(q + VI[b] * H + col);
+        const f32x4 base = 0.5f * (xs[XS[b]] + xs[YS[b]]);
+        st4(c + (12 + b) * H + col, g3[b] * (s3[b] * val) + (1.0f - g3[b]) * base);
+      }
+    }
+  }
+}
+
 // backward of the above.  dcatp: [nsplit][B][16H] partial sums of dCAT.
 template <int NI>
 __global__ __launch_bounds__(256) void coattn_pairs_bwd_kernel(const float* dcatp, int nsplit, const float* cat,
@@ -1036,9 +1145,9 @@ extern "C" int ufnd_fusion_forward(const ufnd_dims* d, const ufnd_fusion_params*
   //    4..14 (:44-54,172-178): one row kernel
   EvPtrs ev;
   for (int b = 0; b < 3; ++b) { ev.w0[b] = p->ev0_w[b]; ev.b0[b] = p->ev0_b[b]; ev.w2[b] = p->ev2_w[b]; ev.b2[b] = p->ev2_b[b]; }
-  if (H == 256) hipLaunchKernelGGL((coattn_pairs_kernel<1, 1>), rows, blk, 0, stream, w.cat, (const float*)w.qkv, w.gate, B, H, w.s, ev, w.evid, forensic);
-  else if (H == 512) hipLaunchKernelGGL((coattn_pairs_kernel<2, 1>), rows, blk, 0, stream, w.cat, (const float*)w.qkv, w.gate, B, H, w.s, ev, w.evid, forensic);
-  else hipLaunchKernelGGL((coattn_pairs_kernel<4, 1>), rows, blk, 0, stream, w.cat, (const float*)w.qkv, w.gate, B, H, w.s, ev, w.evid, forensic);
+  if (H == 256) hipLaunchKernelGGL((coattn_pairs_wg_kernel<1>), dim3(B), blk, 0, stream, w.cat, (const float*)w.qkv, w.gate, B, H, w.s, ev, w.evid, forensic);
+  else if (H == 512) hipLaunchKernelGGL((coattn_pairs_wg_kernel<2>), dim3(B), blk, 0, stream, w.cat, (const float*)w.qkv, w.gate, B, H, w.s, ev, w.evid, forensic);
+  else hipLaunchKernelGGL((coattn_pairs_wg_kernel<4>), dim3(B), blk, 0, stream, w.cat, (const float*)w.qkv, w.gate, B, H, w.s, ev, w.evid, forensic);
   UFND_CHECK_LAUNCH();
   // 4. fuse_mlp.0: (B,16H) x (2H,16H)^T, split-K then bias+GELU(+dropout)             (:122-124)
   {
