@@ -434,6 +434,97 @@ __global__ __launch_bounds__(256) void coattn_pairs_bwd_kernel(const float* dcat
   }
 }
 
+// The same backward, ONE WORKGROUP of 2 NI waves per row (round 3).  Waves [0, NI) ("A", one per 256-column chunk): the co-attention
+// outputs' gradients, the two row reductions (combined over the chunks in LDS, in chunk order), d q / k / v and the gate gradient.
+// Waves [NI, 2 NI) ("B"): the 12 x nsplit partial-sum loads of the pairwise slots and their part of d t / a / v / u, handed to the A
+// wave of the chunk through LDS, which adds the co-attention halves in the one-wave form's order: the same bits, half the loads per
+// wave and twice the waves.
+template <int NI, int NSPLIT>
+__global__ __launch_bounds__(2 * NI * 64) void coattn_pairs_bwd_wg_kernel(const float* dcatp, const float* cat, const float* qkv,
+                                                                          const float* gate, const float* s_in, int B, int H, float* dtavu,
+                                                                          float* dqkv, float* dg, float* dout) {
+  __shared__ float red[NI][8];
+  __shared__ f32x4 dpart[NI][4][64];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int role = w / NI, part = w % NI;
+  const int row = blockIdx.x;
+  const float* c = cat + (size_t)row * 16 * H;
+  const float* q = qkv + (size_t)row * 9 * H;
+  const int QI[3] = {0, 1, 4}, KI[3] = {2, 5, 7}, VI[3] = {3, 6, 8};
+  const int XS[3] = {0, 0, 2}, YS[3] = {2, 1, 3};
+  auto G = [&](int slot, int col) {
+    f32x4 v = ld4(dcatp + (size_t)row * 16 * H + slot * H + col);      // (NSPLIT is a compile-time constant: every partial of every slot in flight together)
+#pragma unroll
+    for (int p = 1; p < NSPLIT; ++p) v += ld4(dcatp + ((size_t)p * B + row) * 16 * H + slot * H + col);
+    return v;
+  };
+  const int col = 4 * lane + 256 * part;
+  const f32x4 gt = ld4(gate + (size_t)row * 4), sv = ld4(s_in + (size_t)row * 4);
+  f32x4 dob[3] = {};
+  float r_dg[3] = {0, 0, 0}, r_ds[3] = {0, 0, 0};
+  if (role == 1) {
+    const f32x4 t = ld4(c + col), a = ld4(c + H + col), v = ld4(c + 2 * H + col), u = ld4(c + 3 * H + col);
+    const f32x4 g4 = G(4, col), g5 = G(5, col), g6 = G(6, col), g7 = G(7, col), g8 = G(8, col), g9 = G(9, col),
+                g10 = G(10, col), g11 = G(11, col);
+    f32x4 sta, stv;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sta[k] = sgn(t[k] - a[k]); stv[k] = sgn(t[k] - v[k]); }
+    dpart[part][0][lane] = G(0, col) + g4 + g5 * a + g6 * sta + g7 + g8 * v + g9 * stv + g10;
+    dpart[part][1][lane] = G(1, col) + g4 + g5 * t - g6 * sta;
+    dpart[part][2][lane] = G(2, col) + g7 + g8 * t - g9 * stv + g11;
+    dpart[part][3][lane] = G(3, col) + g10 + g11;
+  } else {
+    const f32x4 xs[4] = {ld4(c + col), ld4(c + H + col), ld4(c + 2 * H + col), ld4(c + 3 * H + col)};
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      dob[b] = G(12 + b, col);
+      const f32x4 val = ld4(q + VI[b] * H + col);
+      r_dg[b] = dot4(dob[b], sv[b] * val - 0.5f * (xs[XS[b]] + xs[YS[b]]));
+      r_ds[b] = dot4(dob[b], val);
+    }
+#pragma unroll
+    for (int b = 0; b < 3; ++b) { r_dg[b] = wave_sum(r_dg[b]); r_ds[b] = wave_sum(r_ds[b]); }
+    if (lane == 0) {
+#pragma unroll
+      for (int b = 0; b < 3; ++b) { red[part][b] = r_dg[b]; red[part][3 + b] = r_ds[b]; }
+    }
+  }
+  __syncthreads();
+  if (role == 1) return;
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    float sg = red[0][b], ss = red[0][3 + b];
+#pragma unroll
+    for (int pp = 1; pp < NI; ++pp) { sg += red[pp][b]; ss += red[pp][3 + b]; }
+    r_dg[b] = sg;
+    r_ds[b] = ss;
+  }
+  const float inv = 1.0f / sqrtf((float)H);
+  float dscore[3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    const float dgate = r_dg[b];
+    const float ds = gt[b] * r_ds[b];
+    dscore[b] = ds * sv[b] * (1.0f - sv[b]) * inv;
+    r_dg[b] = dgate * gt[b] * (1.0f - gt[b]);  // gradient at the gate's pre-sigmoid output
+  }
+  if (lane == 0 && part == 0) st4(dout + (size_t)row * 4, f32x4{r_dg[0], r_dg[1], r_dg[2], 0.f});
+  float* dq = dqkv + (size_t)row * 9 * H;
+  f32x4 d[4] = {dpart[part][0][lane], dpart[part][1][lane], dpart[part][2][lane], dpart[part][3][lane]};
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    const f32x4 half = (0.5f * (1.0f - gt[b])) * dob[b];
+    d[XS[b]] += half;
+    d[YS[b]] += half;
+    st4(dq + VI[b] * H + col, (gt[b] * sv[b]) * dob[b]);
+    st4(dq + QI[b] * H + col, dscore[b] * ld4(q + KI[b] * H + col));
+    st4(dq + KI[b] * H + col, dscore[b] * ld4(q + QI[b] * H + col));
+  }
+#pragma unroll
+  for (int x = 0; x < 4; ++x) st4(dtavu + ((size_t)x * B + row) * H + col, d[x]);
+  st4(dg + (size_t)row * H + col, G(15, col));
+}
+
 // evidence_proj parameter gradients: one block per co-attention block, thread j = hidden unit.  part == NULL: the whole batch in one
 // pass (gridDim.y = 1).  part != NULL (larger batches): block (b, s) sums rows [s R, (s + 1) R) into part[s][b][5 H + 64] =
 // [dw0 (H x 3) | db0 (H) | dw2 (H) | db2]; gate_param_finish_kernel adds the slices in ascending order.
@@ -1231,9 +1322,13 @@ extern "C" int ufnd_fusion_backward_phase(const ufnd_dims* d, const ufnd_fusion_
   }  // do_head
   if (do_rest) {
   // concat / pairwise / co-attention backward (row-wise)
-  const dim3 slices(ufnd_cdiv(B * (H / 256), 4));       // one wave per 256-column slice of a row
-  NI_DISPATCH(H, coattn_pairs_bwd_kernel, slices, blk, stream, (const float*)w.dcatp, NSPLIT_FUSE0, (const float*)w.cat,
-              (const float*)w.qkv, (const float*)w.gate, (const float*)w.s, B, H, w.dtavu, w.dqkv, w.dg, w.dout);
+  // one workgroup of 2 * (H / 256) waves per row
+  if (H == 256) hipLaunchKernelGGL((coattn_pairs_bwd_wg_kernel<1, NSPLIT_FUSE0>), dim3(B), dim3(128), 0, stream, (const float*)w.dcatp, (const float*)w.cat,
+                                   (const float*)w.qkv, (const float*)w.gate, (const float*)w.s, B, H, w.dtavu, w.dqkv, w.dg, w.dout);
+  else if (H == 512) hipLaunchKernelGGL((coattn_pairs_bwd_wg_kernel<2, NSPLIT_FUSE0>), dim3(B), dim3(256), 0, stream, (const float*)w.dcatp, (const float*)w.cat,
+                                        (const float*)w.qkv, (const float*)w.gate, (const float*)w.s, B, H, w.dtavu, w.dqkv, w.dg, w.dout);
+  else hipLaunchKernelGGL((coattn_pairs_bwd_wg_kernel<4, NSPLIT_FUSE0>), dim3(B), dim3(512), 0, stream, (const float*)w.dcatp, (const float*)w.cat,
+                          (const float*)w.qkv, (const float*)w.gate, (const float*)w.s, B, H, w.dtavu, w.dqkv, w.dg, w.dout);
   UFND_CHECK_LAUNCH();
   // evidence_proj parameter grads
   {
