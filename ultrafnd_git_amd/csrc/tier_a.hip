@@ -128,112 +128,11 @@ struct EvGrads {
   float *w0[3], *b0[3], *w2[3], *b2[3];
 };
 // ---------------------------------------------------------------- co-attention + pairwise -> CAT
-// cross_modal_transformer.py:44-54 and :172-178
-// evidence scalars + gates of a row (shared by the stand-alone kernel above and the fused one below): the same operation
-// sequence, so both give the same bits
-template <int NI>
-__device__ __forceinline__ void evidence_row(const float* c, int H, int lane, const EvPtrs& ev, float (&e3)[3], float (&g)[3]) {
-  float tt = 0, vv = 0, uu = 0, tv = 0, tu = 0, ta = 0;
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int col = 4 * lane + 256 * i;
-    const f32x4 t = ld4(c + col), v = ld4(c + 2 * H + col), u = ld4(c + 3 * H + col);
-    tt += dot4(t, t); vv += dot4(v, v); uu += dot4(u, u); tv += dot4(t, v); tu += dot4(t, u);
-    ta += fabsf(t[0]) + fabsf(t[1]) + fabsf(t[2]) + fabsf(t[3]);
-  }
-  tt = wave_sum(tt); vv = wave_sum(vv); uu = wave_sum(uu); tv = wave_sum(tv); tu = wave_sum(tu); ta = wave_sum(ta);
-  const float nt = fmaxf(sqrtf(tt), 1e-12f), nv = fmaxf(sqrtf(vv), 1e-12f), nu = fmaxf(sqrtf(uu), 1e-12f);
-  const float conf = 1.0f - 0.5f * (fminf(fmaxf(tv / (nt * nv), -1.0f), 1.0f) + 1.0f);
-  const float delay = 1.0f - 0.5f * (fminf(fmaxf(tu / (nt * nu), -1.0f), 1.0f) + 1.0f);
-  const float emo = tanhf(ta / (float)H);
-  e3[0] = conf; e3[1] = emo; e3[2] = delay;
-  const float e[3][3] = {{conf, emo, 0.f}, {emo, 0.f, 0.f}, {delay, 0.f, 0.f}};
-#pragma unroll
-  for (int b = 0; b < 3; ++b) {
-    float o = 0.0f;
-#pragma unroll
-    for (int q4 = 0; q4 < 4 * NI; ++q4) {        // H = 256 NI hidden units, 64 per pass: the parameter loads of all passes fly together
-      const int jj = lane + 64 * q4;
-      const float pre = ev.w0[b][jj * 3 + 0] * e[b][0] + ev.w0[b][jj * 3 + 1] * e[b][1] +
-                        ev.w0[b][jj * 3 + 2] * e[b][2] + ev.b0[b][jj];
-      o += ev.w2[b][jj] * gelu_f(pre);
-    }
-    g[b] = sigmoid_f(wave_sum(o) + ev.b2[b][0]);
-  }
-}
-
-// EVID = 1: the evidence scalars / gates of the row are computed here too (one launch instead of evidence_gate_kernel +
-// this one: the row's t, v, u are read by both anyway) and written to evid / gate_io / forensic.
-template <int NI, int EVID = 0>
-__global__ __launch_bounds__(256) void coattn_pairs_kernel(float* cat, const float* qkv, float* gate_io, int B,
-                                                           int H, float* s_out, EvPtrs ev, float* evid, float* forensic) {
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + w;
-  if (row >= B) return;
-  float* c = cat + (size_t)row * 16 * H;
-  const float* q = qkv + (size_t)row * 9 * H;
-  const float* gate = gate_io;
-  f32x4 gt;
-  if constexpr (EVID) {
-    float e3[3], g3[3];
-    evidence_row<NI>(c, H, lane, ev, e3, g3);
-    gt = f32x4{g3[0], g3[1], g3[2], 0.f};
-    if (lane == 0) {
-      st4(evid + (size_t)row * 4, f32x4{e3[0], e3[1], e3[2], 0.f});
-      st4(gate_io + (size_t)row * 4, gt);
-      forensic[row] = e3[1];              // emotion_intensity
-      forensic[B + row] = e3[0];          // semantic_conflict
-      forensic[2 * B + row] = e3[2];      // temporal_delay
-    }
-  } else {
-    gt = ld4(gate + (size_t)row * 4);
-  }
-  const int QI[3] = {0, 1, 4}, KI[3] = {2, 5, 7}, VI[3] = {3, 6, 8};
-  const int XS[3] = {0, 0, 2}, YS[3] = {2, 1, 3};
-  float dots[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-  for (int b = 0; b < 3; ++b)
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int col = 4 * lane + 256 * i;
-      dots[b] += dot4(ld4(q + QI[b] * H + col), ld4(q + KI[b] * H + col));
-    }
-  float s[3];
-  const float inv = 1.0f / sqrtf((float)H);
-#pragma unroll
-  for (int b = 0; b < 3; ++b) s[b] = sigmoid_f(wave_sum(dots[b]) * inv);
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int col = 4 * lane + 256 * i;
-    const f32x4 t = ld4(c + col), a = ld4(c + H + col), v = ld4(c + 2 * H + col), u = ld4(c + 3 * H + col);
-    f32x4 ab;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) ab[k] = fabsf(t[k] - a[k]);
-    st4(c + 4 * H + col, t + a);
-    st4(c + 5 * H + col, t * a);
-    st4(c + 6 * H + col, ab);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) ab[k] = fabsf(t[k] - v[k]);
-    st4(c + 7 * H + col, t + v);
-    st4(c + 8 * H + col, t * v);
-    st4(c + 9 * H + col, ab);
-    st4(c + 10 * H + col, t + u);
-    st4(c + 11 * H + col, v + u);
-    const f32x4 xs[4] = {t, a, v, u};
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      const f32x4 val = ld4(q + VI[b] * H + col);
-      const f32x4 base = 0.5f * (xs[XS[b]] + xs[YS[b]]);
-      st4(c + (12 + b) * H + col, gt[b] * (s[b] * val) + (1.0f - gt[b]) * base);
-    }
-  }
-  if (lane == 0) st4(s_out + (size_t)row * 4, f32x4{s[0], s[1], s[2], 0.f});
-}
-
-// The same row, ONE WORKGROUP per row (round 3): wave 0 the evidence scalars while waves 1-3 take one co-attention score each; then
+// cross_modal_transformer.py:153-164 (evidence scalars), :48 (evidence gates), :44-54 and :172-178 (co-attention combine, pairwise features).
+// ONE WORKGROUP per row (round 3; one wave per row before): wave 0 the evidence scalars while waves 1-3 take one co-attention score each; then
 // waves 0-2 one evidence gate each (their parameter loads requested before the barrier); then the 11 pairwise / co-attention slots
 // are dealt over the waves by column chunk and slot group.  Every scalar is still one wave's reduction over the same lanes and
-// every element the same expression: the same bits as coattn_pairs_kernel<NI, 1>, a third of its chain.
+// every element the same expression: the same bits as the one-wave form it replaced, a third of its chain.
 template <int NI>
 __global__ __launch_bounds__(256) void coattn_pairs_wg_kernel(float* cat, const float* qkv, float* gate_io, int B, int H, float* s_out,
                                                               EvPtrs ev, float* evid, float* forensic) {
@@ -255,7 +154,7 @@ __global__ __launch_bounds__(256) void coattn_pairs_wg_kernel(float* cat, const 
       pw2[q4] = ev.w2[w][jj];
     }
   }
-  if (w == 0) {          // evidence scalars (evidence_row's first half)
+  if (w == 0) {          // evidence scalars (cross_modal_transformer.py:153-164)
     float tt = 0, vv = 0, uu = 0, tv = 0, tu = 0, ta = 0;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -289,7 +188,7 @@ __global__ __launch_bounds__(256) void coattn_pairs_wg_kernel(float* cat, const 
     if (lane == 0) s_lds[b] = sb;
   }
   __syncthreads();
-  if (w < 3) {           // evidence gate of block w (evidence_row's second half)
+  if (w < 3) {           // evidence gate of block w (cross_modal_transformer.py:48: evidence_proj -> sigmoid)
     const float conf = e_lds[0], emo = e_lds[1], delay = e_lds[2];
     const float e0 = w == 0 ? conf : (w == 1 ? emo : delay), e1 = w == 0 ? emo : 0.f, e2 = 0.f;
     float o = 0.0f;
@@ -339,102 +238,8 @@ __global__ __launch_bounds__(256) void coattn_pairs_wg_kernel(float* cat, const 
   }
 }
 
-// backward of the above.  dcatp: [nsplit][B][16H] partial sums of dCAT.
-template <int NI>
-__global__ __launch_bounds__(256) void coattn_pairs_bwd_kernel(const float* dcatp, int nsplit, const float* cat,
-                                                               const float* qkv, const float* gate, const float* s_in,
-                                                               int B, int H, float* dtavu, float* dqkv, float* dg,
-                                                               float* dout) {
-  // one wave per 256-column slice of a row (NI waves per row, 4 / NI rows per block): at B = 32 the kernel is a
-  // latency chain, so the slices of a row run side by side; the two row reductions meet in LDS, slices added in order
-  constexpr int RPB = 4 / NI;
-  __shared__ float red[4][8];
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int rsub = w / NI, part = w % NI;
-  const bool live = blockIdx.x * RPB + rsub < B;
-  const int row = live ? blockIdx.x * RPB + rsub : B - 1;
-  const float* c = cat + (size_t)row * 16 * H;
-  const float* q = qkv + (size_t)row * 9 * H;
-  const int QI[3] = {0, 1, 4}, KI[3] = {2, 5, 7}, VI[3] = {3, 6, 8};
-  const int XS[3] = {0, 0, 2}, YS[3] = {2, 1, 3};
-  auto G = [&](int slot, int col) {
-    f32x4 v = ld4(dcatp + (size_t)row * 16 * H + slot * H + col);
-    for (int p = 1; p < nsplit; ++p) v += ld4(dcatp + ((size_t)p * B + row) * 16 * H + slot * H + col);
-    return v;
-  };
-  const f32x4 gt = ld4(gate + (size_t)row * 4), sv = ld4(s_in + (size_t)row * 4);
-  // pass 1: the two row reductions of every block
-  float r_dg[3] = {0, 0, 0}, r_ds[3] = {0, 0, 0};
-  const int col = 4 * lane + 256 * part;
-  f32x4 dob[3];                                   // dCAT of the three co-attention outputs: used by both passes
-  {
-    const f32x4 xs[4] = {ld4(c + col), ld4(c + H + col), ld4(c + 2 * H + col), ld4(c + 3 * H + col)};
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      dob[b] = G(12 + b, col);
-      const f32x4 val = ld4(q + VI[b] * H + col);
-      r_dg[b] = dot4(dob[b], sv[b] * val - 0.5f * (xs[XS[b]] + xs[YS[b]]));
-      r_ds[b] = dot4(dob[b], val);
-    }
-  }
-#pragma unroll
-  for (int b = 0; b < 3; ++b) { r_dg[b] = wave_sum(r_dg[b]); r_ds[b] = wave_sum(r_ds[b]); }
-  if constexpr (NI > 1) {
-    if (lane == 0) {
-#pragma unroll
-      for (int b = 0; b < 3; ++b) { red[w][b] = r_dg[b]; red[w][3 + b] = r_ds[b]; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      float sg = red[rsub * NI][b], ss = red[rsub * NI][3 + b];
-#pragma unroll
-      for (int pp = 1; pp < NI; ++pp) { sg += red[rsub * NI + pp][b]; ss += red[rsub * NI + pp][3 + b]; }
-      r_dg[b] = sg;
-      r_ds[b] = ss;
-    }
-  }
-  if (!live) return;
-  const float inv = 1.0f / sqrtf((float)H);
-  float dscore[3];
-#pragma unroll
-  for (int b = 0; b < 3; ++b) {
-    const float dgate = r_dg[b];
-    const float ds = gt[b] * r_ds[b];
-    dscore[b] = ds * sv[b] * (1.0f - sv[b]) * inv;
-    r_dg[b] = dgate * gt[b] * (1.0f - gt[b]);  // gradient at the gate's pre-sigmoid output
-  }
-  if (lane == 0 && part == 0) st4(dout + (size_t)row * 4, f32x4{r_dg[0], r_dg[1], r_dg[2], 0.f});
-  // pass 2
-  float* dq = dqkv + (size_t)row * 9 * H;
-  {
-    const f32x4 t = ld4(c + col), a = ld4(c + H + col), v = ld4(c + 2 * H + col), u = ld4(c + 3 * H + col);
-    const f32x4 g4 = G(4, col), g5 = G(5, col), g6 = G(6, col), g7 = G(7, col), g8 = G(8, col), g9 = G(9, col),
-                g10 = G(10, col), g11 = G(11, col);
-    f32x4 sta, stv;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { sta[k] = sgn(t[k] - a[k]); stv[k] = sgn(t[k] - v[k]); }
-    f32x4 d[4];
-    d[0] = G(0, col) + g4 + g5 * a + g6 * sta + g7 + g8 * v + g9 * stv + g10;
-    d[1] = G(1, col) + g4 + g5 * t - g6 * sta;
-    d[2] = G(2, col) + g7 + g8 * t - g9 * stv + g11;
-    d[3] = G(3, col) + g10 + g11;
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      const f32x4 half = (0.5f * (1.0f - gt[b])) * dob[b];
-      d[XS[b]] += half;
-      d[YS[b]] += half;
-      st4(dq + VI[b] * H + col, (gt[b] * sv[b]) * dob[b]);
-      st4(dq + QI[b] * H + col, dscore[b] * ld4(q + KI[b] * H + col));
-      st4(dq + KI[b] * H + col, dscore[b] * ld4(q + QI[b] * H + col));
-    }
-#pragma unroll
-    for (int x = 0; x < 4; ++x) st4(dtavu + ((size_t)x * B + row) * H + col, d[x]);
-    st4(dg + (size_t)row * H + col, G(15, col));
-  }
-}
-
-// The same backward, ONE WORKGROUP of 2 NI waves per row (round 3).  Waves [0, NI) ("A", one per 256-column chunk): the co-attention
+// backward of the above.  dcatp: [NSPLIT][B][16H] partial sums of dCAT.
+// ONE WORKGROUP of 2 NI waves per row (round 3; one wave per 256-column slice before).  Waves [0, NI) ("A", one per 256-column chunk): the co-attention
 // outputs' gradients, the two row reductions (combined over the chunks in LDS, in chunk order), d q / k / v and the gate gradient.
 // Waves [NI, 2 NI) ("B"): the 12 x nsplit partial-sum loads of the pairwise slots and their part of d t / a / v / u, handed to the A
 // wave of the chunk through LDS, which adds the co-attention halves in the one-wave form's order: the same bits, half the loads per
