@@ -475,7 +475,11 @@ int launch_nt(const NtProb* probs, int nprob, const ufnd_step_state* st, hipStre
     a.p[i] = p;
     maxM = p.M > maxM ? p.M : maxM;
   }
-  const int MT = maxM > 32 ? 2 : 1;
+  // two 32-row tiles per workgroup (the weight tile is read once for 64 rows) only when the launch still fills the chip that way:
+  // the fp32 MFMA rate is per SIMD, so a launch of a few dozen workgroups is matrix-bound on the CUs it occupies
+  int blocks1 = 0;
+  for (int i = 0; i < nprob; ++i) blocks1 += (a.p[i].N / 32) * ufnd_cdiv(a.p[i].M, 32) * a.p[i].ksplit;
+  const int MT = (maxM > 32 && blocks1 >= 512) ? 2 : 1;
   for (int i = 0; i < nprob; ++i) {
     a.begin[i] = total;
     total += (a.p[i].N / 32) * ufnd_cdiv(a.p[i].M, 32 * MT) * a.p[i].ksplit;
@@ -518,7 +522,10 @@ int launch_nn(const NnProb* probs, int nprob, const ufnd_step_state* st, hipStre
   // A wave's MFMA chain is (contraction / 32) * VEC long at 64 cycles each: when a launch has only a
   // handful of blocks, narrow the strips (more blocks, shorter chains) -- the work is latency-, not
   // bandwidth-bound at that size.
+  // (the fp32 MFMA rate is per SIMD: with few workgroups the launch is matrix-bound on the CUs it occupies, so the strips narrow
+  //  until the launch has about one workgroup per CU)
   if (count(VEC) < 64) VEC = 1;
+  else if (count(VEC) < 256) VEC = (VEC == 4 && count(2) >= 256) ? 2 : 1;
   int total = 0;
   for (int i = 0; i < nprob; ++i) {
     a.begin[i] = total;
