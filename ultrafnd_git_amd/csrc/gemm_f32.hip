@@ -176,6 +176,96 @@ __global__ __launch_bounds__(256) void nt_kernel(const NtArgs args) {
 }
 
 // ------------------------------------------------------------------------------------------
+// NT on 16x16 tiles (v_mfma_f32_16x16x4_f32), for launches that are too small to fill the chip with 32x32 tiles (round 3).
+// The fp32 MFMA rate is per SIMD, so a 32-row batch against N = 512 outputs -- 16 tiles of 32x32 -- runs its whole contraction
+// on 16 CUs: 128 dependent MFMAs per wave at K = 1,024.  With 16x16 tiles the same launch has 64 workgroups and a quarter of
+// the chain per wave.  Operand maps: A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15]; C/D: column j = l & 15, row 4 (l >> 4) + r.
+// A lane loads four consecutive contraction elements (16 B) and feeds element e to MFMA step e (a chunk = 16 contraction
+// elements = 4 MFMAs); rows n of W are the A operand, batch rows m the B operand, so a lane ends with four consecutive n of one m.
+// The four waves split the K range; their partial tiles are added in wave order in LDS and wave 0 runs the epilogue.
+// ------------------------------------------------------------------------------------------
+template <int WVEC>
+__global__ __launch_bounds__(256) void nt16_kernel(const NtArgs args) {
+  __shared__ float red[4][4][64];
+  int pi = 0;
+  for (int q = 1; q < args.nprob; ++q)
+    if ((int)blockIdx.x >= args.begin[q]) pi = q;
+  const NtProb& P = args.p[pi];
+  int local = blockIdx.x - args.begin[pi];
+  const int n_tiles = P.N >> 4;
+  const int n0 = (local % n_tiles) << 4;
+  const int m0 = (local / n_tiles) << 4;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  // K range of this wave (multiples of 16 except at the very end of K); ksplit == 1 in this form
+  int sub = (P.K + 3) / 4;
+  sub = (sub + 15) & ~15;
+  const int k0 = min(P.K, w * sub), k1 = min(P.K, k0 + sub);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float* wrow = P.W + (size_t)(n0 + j) * P.ldw;
+  const int m = m0 + j;
+  const bool xok = m < P.M;
+  const float* xrow = P.X + (size_t)(xok ? m : 0) * P.ldx;
+  constexpr int U = 8;      // 8 chunks = 128 contraction elements per batch: 16 loads of 16 B in flight, then 32 MFMAs
+  int k = k0;
+  for (; k + 16 * U <= k1; k += 16 * U) {
+    float a[U][4], b[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int kk = k + 16 * u + 4 * g;
+      load_vec<WVEC>(wrow + kk, a[u]);
+      if (xok) {
+        load_vec<4>(xrow + kk, b[u]);
+      } else {
+        b[u][0] = b[u][1] = b[u][2] = b[u][3] = 0.0f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], b[u][e], acc, 0, 0, 0);
+  }
+  for (; k + 16 <= k1; k += 16) {
+    const int kk = k + 4 * g;
+    float a[4], b[4] = {0.f, 0.f, 0.f, 0.f};
+    load_vec<WVEC>(wrow + kk, a);
+    if (xok) load_vec<4>(xrow + kk, b);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
+  }
+  if (k < k1) {  // ragged tail (K not a multiple of 16), element-guarded
+    const int kk = k + 4 * g;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool ok = (kk + e) < k1;
+      const float a = ok ? wrow[kk + e] : 0.0f;
+      const float b = (ok && xok) ? xrow[kk + e] : 0.0f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[w][r][lane] = acc[r];
+  __syncthreads();
+  if (w != 0 || !xok) return;
+  f32x4 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = ((red[0][r][lane] + red[1][r][lane]) + red[2][r][lane]) + red[3][r][lane];
+  const int n = n0 + 4 * g;      // this lane: outputs n .. n + 3 of batch row m
+  if (P.bias) v += *reinterpret_cast<const f32x4*>(P.bias + n);
+  if (P.Z) *reinterpret_cast<f32x4*>(P.Z + (size_t)m * P.ldz + n) = v;
+  if (P.act == 1) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = gelu_f(v[q]);
+  }
+  if (P.drop_p > 0.0f) {
+    float dm[4];
+    dropout_mul4(args.st, P.drop_p, P.drop_layer, (uint32_t)(m * P.N + n), dm);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] *= dm[q];
+  }
+  *reinterpret_cast<f32x4*>(P.Y + (size_t)m * P.ldy + n) = v;
+}
+
+// ------------------------------------------------------------------------------------------
 // NN: dX = dY W  (contraction over the weight's ROW index n; weight rows stream coalesced).
 // A wave owns a strip of 32*VEC output columns (lane j owns columns kc + VEC*j .. +VEC-1).
 // ------------------------------------------------------------------------------------------
@@ -308,6 +398,72 @@ __global__ __launch_bounds__(256) void nn_kernel(const NnArgs args) {
     float* dst = P.out + (size_t)mrow * P.ldo + kcol;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) dst[v] = val[v];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// NN on 16x16 tiles (v_mfma_f32_16x16x4_f32) for narrow layers (see nt16_kernel): tile = 16 batch rows x 16 output columns.
+// A = dY rows (lane (i, g) loads dY[m0 + i][n + 4 g .. + 3] as 16 B), B = W[n + 4 g + e][kcol0 + j] (four 4-B loads, 16 lanes
+// contiguous); C/D: column kcol0 + (l & 15), rows m0 + 4 (l >> 4) + r.  The four waves split the contraction range, partial
+// tiles are added in wave order in LDS, wave 0 runs the epilogue.  nsplit == 1 only.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nn16_kernel(const NnArgs args) {
+  __shared__ float red[4][4][64];
+  int pi = 0;
+  for (int q = 1; q < args.nprob; ++q)
+    if ((int)blockIdx.x >= args.begin[q]) pi = q;
+  const NnProb& P = args.p[pi];
+  const int local = blockIdx.x - args.begin[pi];
+  const int strips = (P.K + 15) >> 4;
+  const int kc = (local % strips) << 4;
+  const int m0 = (local / strips) << 4;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  int sub = (P.N + 3) / 4;
+  sub = (sub + 15) & ~15;
+  const int n0 = min(P.N, w * sub), n1 = min(P.N, n0 + sub);      // N % 32 == 0 (host-checked) => multiples of 16
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int m = m0 + j;
+  const bool mok = m < P.M;
+  const float* dyrow = P.dY + (size_t)(mok ? m : 0) * P.lddy;
+  const int kcol = kc + j;
+  const bool kok = kcol < P.K;
+  const float* wcol = P.W + (kok ? kcol : 0);
+  constexpr int U = 4;      // 4 chunks = 64 contraction rows per batch: 4 + 16 loads in flight, then 16 MFMAs
+  for (int n = n0; n < n1; n += 16 * U) {
+    float a[U][4], b[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int nn = n + 16 * u + 4 * g;
+      const bool nok = (n + 16 * u) < n1;
+      if (mok && nok) {
+        load_vec<4>(dyrow + nn, a[u]);
+      } else {
+        a[u][0] = a[u][1] = a[u][2] = a[u][3] = 0.0f;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) b[u][e] = (kok && nok) ? wcol[(size_t)(nn + e) * P.ldw] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], b[u][e], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[w][r][lane] = acc[r];
+  __syncthreads();
+  if (w != 0 || !kok) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int mrow = m0 + 4 * g + r;
+    if (mrow >= P.M) continue;
+    float val = ((red[0][r][lane] + red[1][r][lane]) + red[2][r][lane]) + red[3][r][lane];
+    if (P.actZ) {
+      float gz = gelu_grad_f(P.actZ[(size_t)mrow * P.ldz + kcol]);
+      if (P.drop_p > 0.0f) gz *= dropout_mul(args.st, P.drop_p, P.drop_layer, (uint32_t)(mrow * P.drop_ld + kcol));
+      val *= gz;
+    }
+    if (P.add) val += P.add[(size_t)mrow * P.ldadd + kcol];
+    P.out[(size_t)mrow * P.ldo + kcol] = val;
   }
 }
 
@@ -475,6 +631,26 @@ int launch_nt(const NtProb* probs, int nprob, const ufnd_step_state* st, hipStre
     a.p[i] = p;
     maxM = p.M > maxM ? p.M : maxM;
   }
+  {      // narrow layers: 16x16 tiles (four times the workgroups, a quarter of the MFMA chain per wave).  The choice looks at the
+         // layers' widths only, never at the batch: a row's arithmetic must not depend on the batch it is computed in
+    int t32 = 0;
+    bool plain = true;
+    for (int i = 0; i < nprob; ++i) {
+      t32 += a.p[i].N / 32;
+      if (a.p[i].ksplit != 1) plain = false;
+    }
+    if (plain && t32 <= 128) {
+      for (int i = 0; i < nprob; ++i) {
+        a.begin[i] = total;
+        total += (a.p[i].N / 16) * ufnd_cdiv(a.p[i].M, 16);
+      }
+      a.begin[nprob] = total;
+      if (vec4) hipLaunchKernelGGL((nt16_kernel<4>), dim3(total), dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((nt16_kernel<2>), dim3(total), dim3(256), 0, stream, a);
+      UFND_CHECK_LAUNCH();
+      return UFND_OK;
+    }
+  }
   // two 32-row tiles per workgroup (the weight tile is read once for 64 rows) only when the launch still fills the chip that way:
   // the fp32 MFMA rate is per SIMD, so a launch of a few dozen workgroups is matrix-bound on the CUs it occupies
   int blocks1 = 0;
@@ -512,6 +688,25 @@ int launch_nn(const NnProb* probs, int nprob, const ufnd_step_state* st, hipStre
     UFND_REQUIRE((long long)p.M * p.K < (1ll << 31), "nn[%d]: M*K too large", i);
     if (!(p.K % 4 == 0 && p.ldw % 4 == 0 && ufnd_aligned(p.W, 16))) vec4 = false;
     a.p[i] = p;
+  }
+  {      // narrow layers: 16x16 tiles (chosen by the layers' widths only, never by the batch: see launch_nt)
+    int s32 = 0;
+    bool plain = true;
+    for (int i = 0; i < nprob; ++i) {
+      s32 += ufnd_cdiv(a.p[i].K, 32);
+      if (a.p[i].nsplit != 1) plain = false;
+    }
+    if (plain && s32 <= 128) {
+      int total = 0;
+      for (int i = 0; i < nprob; ++i) {
+        a.begin[i] = total;
+        total += ufnd_cdiv(a.p[i].K, 16) * ufnd_cdiv(a.p[i].M, 16);
+      }
+      a.begin[nprob] = total;
+      hipLaunchKernelGGL(nn16_kernel, dim3(total), dim3(256), 0, stream, a);
+      UFND_CHECK_LAUNCH();
+      return UFND_OK;
+    }
   }
   int VEC = vec4 ? 4 : 2;
   auto count = [&](int vec) {
