@@ -27,6 +27,8 @@ def diag() -> C.CDLL:
         d.ufnd_diag_gemm_bf16_stamps.restype = I
         d.ufnd_diag_qkv_attention_stamps.argtypes = [P, P, P, P, P, I, I, C.POINTER(L.GemmLn), P, P]
         d.ufnd_diag_qkv_attention_stamps.restype = I
+        d.ufnd_diag_gemm_pp_stamps.argtypes = [P, P, P, I, I, I, P, C.POINTER(L.GemmLn), P, I, I, P]
+        d.ufnd_diag_gemm_pp_stamps.restype = I
         d.ufnd_diag_where.argtypes = [P, I, C.c_uint64, P]
         d.ufnd_diag_where.restype = I
         _d = d

@@ -45,6 +45,7 @@ def _digest(extra: str) -> str:
     h = hashlib.sha256()
     h.update(extra.encode())
     h.update(" ".join(_defs()).encode())       # an experimental -D build is never mistaken for the current one
+    h.update(repr(sorted(FILE_FLAGS.items())).encode())
     files = sorted(list(CSRC.glob("*")) + list((CSRC / "diag").glob("*")) + [PKG.parent / "include" / "ultrafnd_hip.h"])
     for f in files:
         if f.is_file():
@@ -53,10 +54,17 @@ def _digest(extra: str) -> str:
     return h.hexdigest()
 
 
+# per-file switches.  The persistent GEMM is built without packed fp32 instructions (csrc/gemm_bf16_pp.hip says why); the feature
+# switch reaches the host pass of hipcc too, which answers "not a recognized feature for this target (ignoring feature)".
+FILE_FLAGS = {"gemm_bf16_pp": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"],
+              "gemm_pp_diag": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]}
+
+
 def _compile(src: Path, tag: str, flags: list, verbose: bool) -> Path:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     obj = OBJ / f"{tag}_{src.stem}.o"
     cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-c", str(src), "-o", str(obj)] + flags + _defs()
+    cmd += FILE_FLAGS.get(src.stem, [])
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))

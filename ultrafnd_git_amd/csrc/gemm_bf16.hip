@@ -3,6 +3,11 @@
 // diag/gemm_diag.hip (libultrafnd_hip_diag.so).
 #include "gemm_bf16_kernel.hpp"
 
+// the persistent, software-pipelined form (gemm_bf16_pp.hpp), compiled in gemm_bf16_pp.hip
+#define UFND_GEMM_TILE_PP 64
+int ufnd_pp_pick(const void* gemm_args);
+int ufnd_pp_launch(void* gemm_args, void* stream);
+
 namespace {
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* src, __bf16* dst, size_t n) {
   for (size_t i = (blockIdx.x * (size_t)256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 256 * 4) {
@@ -31,6 +36,7 @@ extern "C" int ufnd_gemm_bf16_ex(const void* A, const void* W, const float* bias
   UFND_REQUIRE(!bias || ufnd_aligned(bias, 4), "gemm_bf16: bias alignment");
   UFND_REQUIRE(act >= 0 && act <= 2, "gemm_bf16: act=%d", act);
   GemmArgs a{(const __bf16*)A, (const __bf16*)W, bias, residual, (__bf16*)out_bf16, out_f32, M, N, K, lda, ldw, ldr, ldo, ldf, act, 0, 0, nullptr};
+  if (tile_cfg == UFND_GEMM_TILE_PP || (tile_cfg < 0 && ufnd_pp_pick(&a))) return ufnd_pp_launch(&a, stream_);      // the persistent, software-pipelined form
   const int cfg = tile_cfg < 0 ? auto_cfg(M, N, K) : tile_cfg;
   UFND_REQUIRE(cfg < kNumTiles && kTiles[cfg].built, "gemm_bf16: tile config %d is not part of this library (ufnd_gemm_bf16_tile_info)", cfg);
   UFND_REQUIRE(N % kTiles[cfg].bn == 0, "gemm_bf16: tile config %d needs N %% %d == 0", cfg, kTiles[cfg].bn);
@@ -55,7 +61,9 @@ static int stat_parts_for(int cfg, int N) {
   if (!t.built || !t.lnx || N % t.bn != 0 || tn % 32 != 0 || (N / 32) % 2 != 0 || N / 32 > 24) return 0;
   return N / 32;
 }
-extern "C" int ufnd_gemm_bf16_stat_parts(int M, int N, int K) { return stat_parts_for(auto_cfg(M, N, K), N); }
+extern "C" int ufnd_gemm_bf16_stat_parts(int M, int N, int K) {
+  return stat_parts_for(auto_cfg(M, N, K), N);      // (the persistent form is never the automatic choice of a call with out_stats)
+}
 
 extern "C" int ufnd_gemm_bf16_ln(const void* A, const void* W, const float* bias, const float* residual, void* out_bf16,
                                  float* out_f32, int M, int N, int K, int lda, int ldw, int ldr, int ldo, int ldf, int act,
@@ -85,12 +93,6 @@ extern "C" int ufnd_gemm_bf16_ln(const void* A, const void* W, const float* bias
                      ufnd_aligned(ln->r_stats, 16), "gemm_bf16_ln: r_stats needs residual, r_gamma, r_beta (16-B aligned)");
     UFND_REQUIRE(ln->r_parts >= 2 && ln->r_parts <= 24 && ln->r_parts % 2 == 0, "gemm_bf16_ln: r_parts=%d (even, 2..24)", ln->r_parts);
   }
-  const int cfg = ln->tile_cfg < 0 ? auto_cfg(M, N, K) : ln->tile_cfg;
-  UFND_REQUIRE(cfg < kNumTiles && kTiles[cfg].built && kTiles[cfg].lnx && N % kTiles[cfg].bn == 0,
-               "gemm_bf16_ln: no LayerNorm-aware kernel for M=%d N=%d K=%d (tile %d)", M, N, K, cfg);
-  if (ln->out_stats) {
-    UFND_REQUIRE(stat_parts_for(cfg, N) > 0 && ufnd_aligned(ln->out_stats, 16), "gemm_bf16_ln: out_stats unsupported for this shape / tile");
-  }
   GemmArgs a{(const __bf16*)A, (const __bf16*)W, bias, residual, (__bf16*)out_bf16, out_f32, M, N, K, lda, ldw, ldr, ldo, ldf, act, 0, 0, nullptr};
   a.a_stats = ln->a_stats; a.colsum = ln->colsum; a.r_stats = ln->r_stats; a.r_gamma = ln->r_gamma; a.r_beta = ln->r_beta;
   a.out_stats = ln->out_stats; a.a_parts = ln->a_parts; a.r_parts = ln->r_parts; a.a_eps = ln->a_eps; a.r_eps = ln->r_eps;
@@ -98,6 +100,13 @@ extern "C" int ufnd_gemm_bf16_ln(const void* A, const void* W, const float* bias
   a.residual_b = (const __bf16*)ln->residual_bf16;
   a.ldrb = ln->ldrb;
   a.guard = ln->a_stats ? ln->guard : nullptr;
+  if (ln->tile_cfg == UFND_GEMM_TILE_PP || (ln->tile_cfg < 0 && ufnd_pp_pick(&a))) return ufnd_pp_launch(&a, stream_);      // the persistent, software-pipelined form
+  const int cfg = ln->tile_cfg < 0 ? auto_cfg(M, N, K) : ln->tile_cfg;
+  UFND_REQUIRE(cfg < kNumTiles && kTiles[cfg].built && kTiles[cfg].lnx && N % kTiles[cfg].bn == 0,
+               "gemm_bf16_ln: no LayerNorm-aware kernel for M=%d N=%d K=%d (tile %d)", M, N, K, cfg);
+  if (ln->out_stats) {
+    UFND_REQUIRE(stat_parts_for(cfg, N) > 0 && ufnd_aligned(ln->out_stats, 16), "gemm_bf16_ln: out_stats unsupported for this shape / tile");
+  }
   int rc = launch_cfg(cfg, 4, a, (hipStream_t)stream_);
   if (rc != UFND_OK) return rc;
   UFND_CHECK_LAUNCH();

@@ -70,6 +70,7 @@ struct GemmArgs {
   // fold guard (LNX kernels with a_stats): 1,024 floats; every workgroup leaves the largest |mean| * rstd among the rows it
   // normalises in slot blockIdx.x % 1024 (one atomicMax at its very end: non-negative floats order like ints)
   float* guard;
+  int pp_rows;               // persistent form (gemm_bf16_pp.hpp): row panels per tile group of the walk order
 };
 
 __device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst) {
