@@ -38,8 +38,15 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
+torch = None      # imported by the RANKS only (main(), behind the launcher branch): the launcher process never loads torch, so
+dist = None       # nothing in it can initialise the GPU -- by construction, not by what a particular ROCm build's device query does
+
+
+def _import_torch():
+    global torch, dist
+    import torch as _torch
+    import torch.distributed as _dist
+    torch, dist = _torch, _dist
 
 SEQ_LEN, IMAGE, FRAMES = 128, 224, 1
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
@@ -239,28 +246,45 @@ def bench_train_encoders(args, dev, world, rank):
         dist.destroy_process_group()
 
 
-def launch_command(n: int, argv: list, port: int) -> list:
-    """The torchrun command line `python bench.py --gpus n ...` turns itself into (one rank per GPU, RCCL over xGMI)."""
-    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-            "--master-port", str(port), str(Path(__file__).resolve())] + [a for a in argv if a != "--dry-launch"]
+def count_gpus_sysfs(root: str = "/sys/class/kfd/kfd/topology/nodes") -> int:
+    """GPUs of this node from the KFD topology: nodes whose `properties` file has simd_count > 0 (CPU nodes have 0).  Plain file
+    reads: no HIP / torch call, so the launcher stays GPU-free whatever the ROCm build's device query would do.  Falls back to
+    counting /dev/dri/renderD* when the topology is absent (0 when neither exists)."""
+    n = 0
+    base = Path(root)
+    if base.is_dir():
+        for node in base.iterdir():
+            try:
+                props = dict(line.split()[:2] for line in (node / "properties").read_text().splitlines() if len(line.split()) >= 2)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        return n
+    dri = Path("/dev/dri")
+    return len(list(dri.glob("renderD*"))) if dri.is_dir() else 0
+
+
+def launch_command(n: int, argv: list) -> list:
+    """The torchrun command line `python bench.py --gpus n ...` turns itself into (one rank per GPU, RCCL over xGMI).  A
+    standalone rendezvous on 127.0.0.1: torchrun binds its own free port (no pick-then-bind race)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--standalone", "--local-addr", "127.0.0.1",
+            str(Path(__file__).resolve())] + [a for a in argv if a != "--dry-launch"]
 
 
 def self_launch(args) -> None:
-    """--gpus N > 1 without a RANK in the environment: become the launcher.  Nothing in THIS process touches the GPU
-    (torch.cuda.device_count() does not initialise it on this image), so the ranks are ordinary children; their stdout
-    (rank 0's JSON line) and stderr pass through, and this process exits with torchrun's return code."""
-    import socket
+    """--gpus N > 1 (or --self-launch at N = 1) without a RANK in the environment: become the launcher.  THIS process never
+    imports torch and makes no HIP call (the device count comes from sysfs), so the ranks are ordinary children of a GPU-free
+    parent; their stdout (rank 0's JSON line) and stderr pass through, and this process exits with torchrun's return code."""
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = launch_command(args.gpus, sys.argv[1:], port)
+    assert "torch" not in sys.modules, "the launcher must stay torch-free"
+    cmd = launch_command(args.gpus, sys.argv[1:])
     if args.dry_launch:
         print(json.dumps({"dry_launch": cmd}))
         raise SystemExit(0)
-    have = torch.cuda.device_count()
+    have = count_gpus_sysfs()
     if have < args.gpus:
-        print(f"[bench] --gpus {args.gpus} but this node has {have} HIP device(s): refusing to measure fewer ranks than asked for",
+        print(f"[bench] --gpus {args.gpus} but this node has {have} HIP device(s) (KFD topology): refusing to measure fewer ranks than asked for",
               file=sys.stderr)
         raise SystemExit(3)
     env = dict(os.environ)
@@ -298,10 +322,16 @@ def main():
                     help="secondary measurement: fine-tune both encoders with the head (forward with saved activations + hand-written "
                          "backward; the reference keeps its encoders frozen)")
     ap.add_argument("--dry-launch", action="store_true", help="--gpus N > 1 started plainly: print the torchrun command it would start, start nothing")
+    ap.add_argument("--self-launch", action="store_true",
+                    help="take the launcher branch at any N (N = 1 on a one-GPU box: the torchrun spawn path, RCCL at world 1 with the "
+                         "exchange forced, so that `exchange` reports a measured all-reduce)")
     args = ap.parse_args()
 
-    if args.gpus > 1 and "RANK" not in os.environ:
-        self_launch(args)                       # (never returns)
+    if (args.gpus > 1 or args.self_launch) and "RANK" not in os.environ:
+        self_launch(args)                       # (never returns; torch is not imported yet)
+    _import_torch()
+    if args.self_launch:      # (a rank started by the launcher branch: the flag travels with the arguments)
+        args.force_exchange = True
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

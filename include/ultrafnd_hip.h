@@ -262,8 +262,9 @@ int ufnd_gemm_bf16_ex(const void* A, const void* W, const float* bias, const flo
  * (1 + |mean| / std) * 2^-9 (measured: tests/test_gpu_tier_b.py::test_gemm_ln_fold_error_grows_with_the_row_offset).
  * Rows of trained BERT / CLIP streams have |mean| / std well below 1; ufnd_ln_fold_guard (below) reports the largest
  * ratio in a statistics buffer so that a caller can fall back to a materialised LayerNorm (ufnd_layernorm +
- * ufnd_gemm_bf16) when it is not.  (It is a kernel of its own: an atomic inside the GEMM -- tried -- sits in front of
- * the K loop's counted vmcnt waits and cost 10 us per launch.)
+ * ufnd_gemm_bf16) when it is not; the folding GEMM itself reports the same ratio through ufnd_gemm_ln.guard (below: the reduction
+ * in its prologue, ONE atomicMax per workgroup at the kernel's very end -- an atomic in the prologue sits in front of the K loop's
+ * counted vmcnt waits and cost 10 us per launch).  A non-finite statistic reports +inf.
  * Replaces nn.LayerNorm + nn.Linear pairs of the third-party encoders (transformers modeling_bert.py
  * BertSelfOutput / BertOutput, modeling_clip.py CLIPEncoderLayer) behind text_blocks.py:79. */
 typedef struct ufnd_gemm_ln {

@@ -177,3 +177,51 @@ def test_trainer_step_with_trainable_encoders_vs_oracle(tmp_path):
     tr._load_batch(tr.head.bufs(B, False), gb, "val")
     torch.cuda.synchronize()
     assert (tr.head.bufs(B, False)["text"] - f_train).abs().max().item() <= 2e-3
+
+
+def test_best_checkpoint_carries_the_trained_encoders(tmp_path):
+    """with train_encoders the best-epoch head is only meaningful with that epoch's encoders.  The checkpoint written
+    at the best epoch holds both; after further steps have moved head AND encoders, _load_checkpoint() (what test() runs first)
+    brings back exactly the logits of the saved state -- through the frozen fast path, whose packed operands must be rebuilt."""
+    from oracle import encoders_ref as E
+    from oracle import tier_a as O
+    from ultrafnd_git_amd.dp import save_checkpoint
+    from ultrafnd_git_amd.encoders import BertTextEncoder, ClipVisualEncoder
+    from ultrafnd_git_amd.trainer import ForensicTrainer, TrainConfig, synthetic_cache
+    B, Lq = 4, 64
+    tenc, venc = BertTextEncoder(layers=1, vocab_size=300), ClipVisualEncoder(layers=1)
+    tenc.load_state_dict(E.seeded_weights(E.bert_shapes(layers=1, vocab=300), 21))
+    venc.load_state_dict(E.seeded_weights(E.vit_shapes(layers=1), 22))
+    tenc, venc = tenc.to(DEV), venc.to(DEV)
+    ids, mask = E.synthetic_tokens(23, B, Lq, vocab=300, min_len=8)
+    frames = E.synthetic_frames(24, B, 1)
+    cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir=str(tmp_path), batch_size=B, device=DEV, use_graph=False, encode_inline=True,
+                      train_encoders=True, lr=5e-3)
+    tr = ForensicTrainer(cfg, cache=synthetic_cache(16, seed=1), text_encoder=tenc, visual_encoder=venc)
+    gb = {k: v.to(DEV) for k, v in O.seeded_batch(25, B).items()}
+    gb.update({"input_ids": ids.to(DEV), "attention_mask": mask.to(torch.int32).to(DEV), "frames": frames.to(DEV)})
+
+    def logits():
+        tr.fusion.eval(); tr.clf.eval()
+        out = tr._forward_batch(gb, "val")      # the frozen fast path (packed operands), as validation / test() run it
+        torch.cuda.synchronize()
+        tr.fusion.train(); tr.clf.train()
+        return out["logits"].float().clone()
+
+    tr.fusion.train(); tr.clf.train()
+    for _ in range(2):
+        tr.train_step(gb)
+    want = logits()
+    enc_before = tr.arena.view("text.encoder.layer.0.output.dense.weight").clone()
+    save_checkpoint(tr._checkpoint_state(), tr.ckpt_path, tr.comm)
+    ck = torch.load(tr.ckpt_path, map_location="cpu", weights_only=True)
+    assert "text_encoder" in ck and "visual_encoder" in ck and set(ck["text_encoder"]) == set(tenc.state_dict())
+    for _ in range(3):      # "later epochs": head and encoders both move
+        tr.train_step(gb)
+    assert (tr.arena.view("text.encoder.layer.0.output.dense.weight") - enc_before).abs().max().item() > 1e-4
+    moved = logits()
+    assert (moved - want).abs().max().item() > 1e-4
+    assert tr._load_checkpoint()
+    got = logits()
+    assert torch.equal(tr.arena.view("text.encoder.layer.0.output.dense.weight"), enc_before)
+    assert (got - want).abs().max().item() <= 1e-6, (got - want).abs().max().item()

@@ -340,7 +340,9 @@ void gemm_bf16_kernel(const GemmArgs a) {
       const float rstd = __builtin_amdgcn_rsqf(__fadd_rn(var, a.a_stats ? a.a_eps : a.r_eps));   // v_rsq_f32 (1 ulp, the same instruction in every tile shape)
       if (threadIdx.x % TPR == 0) st_lds[threadIdx.x / TPR] = f32x2{mean, rstd};
       if (a.guard && a.a_stats) {      // fold guard: the largest |mean| / std among the rows this workgroup folds (reported at the kernel's end)
-        const float worst = wave_max(threadIdx.x % TPR == 0 ? __fmul_rn(fabsf(mean), rstd) : 0.0f);
+        float ratio = __fmul_rn(fabsf(mean), rstd);
+        ratio = ratio == ratio ? ratio : INFINITY;      // (a NaN statistic must trip the guard: fmaxf would drop it)
+        const float worst = wave_max(threadIdx.x % TPR == 0 ? ratio : 0.0f);
         if (lane == 0) reinterpret_cast<float*>(smem + STAT_OFF + BM * 8)[wave] = worst;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

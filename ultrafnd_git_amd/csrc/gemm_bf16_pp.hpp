@@ -286,7 +286,11 @@ void gemm_pp_kernel(const GemmArgs a) {
       const float var = fmaxf(__fmaf_rn(-mean, mean, __fmul_rn(sq, a.inv_h)), 0.f);
       const float rstd = __builtin_amdgcn_rsqf(__fadd_rn(var, stat_eps));
       if (sub == 0) st_lds[tid >> 1] = f32x2{mean, rstd};
-      if constexpr (MODE == FOLD) guard_max = fmaxf(guard_max, sub == 0 ? __fmul_rn(fabsf(mean), rstd) : 0.0f);
+      if constexpr (MODE == FOLD) {
+        float ratio = __fmul_rn(fabsf(mean), rstd);
+        ratio = ratio == ratio ? ratio : INFINITY;      // (a NaN statistic must trip the guard: fmaxf would drop it)
+        guard_max = fmaxf(guard_max, sub == 0 ? ratio : 0.0f);
+      }
     }
     {
       const int which = wave >> 1;

@@ -379,15 +379,23 @@ class BertTextEncoder(_EncoderBase):
     @torch.no_grad()
     def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, unpad: bool = False, strict: bool = False) -> torch.Tensor:
         """Batched BERTContextEncoder.encode: (B,L) ids/mask -> (B,768) L2-normalised features.
-        strict=True checks the fold guard after the pass (one host sync) and, if it tripped, repeats the batch with
-        materialised LayerNorms -- for offline feature building; not for hipGraph capture.
+        strict=True is the offline feature builder's mode: fp32 residual stream (whatever `residual_dtype` says), the fold guard checked
+        after the pass (one host sync) and, if it tripped, the batch repeated with materialised LayerNorms; not for hipGraph capture.
         unpad=True runs the encoder over the kept tokens only (packed rows, per-sequence attention): the padded
         positions never reach the pooling (text_blocks.py:82-86), so no returned value changes -- bit-identical for
         prefix masks -- while the work drops with the padding fraction.  Shapes vary per batch: not for hipGraph capture."""
-        if strict and self.fold_ln:
-            out = self.forward(input_ids, attention_mask, unpad=unpad)
-            if not self.check_fold():
-                return out
+        if strict:
+            # the offline feature builder (encode_fields; caches for the reference-style training mode): the more faithful fp32
+            # residual stream whatever the in-step default is -- the bf16 stream's speed only matters inside the train step (ADVICE r3)
+            rd, self.residual_dtype = self.residual_dtype, "fp32"
+            try:
+                if self.fold_ln:
+                    out = self.forward(input_ids, attention_mask, unpad=unpad)
+                    if not self.check_fold():
+                        return out
+                return self.forward(input_ids, attention_mask, unpad=unpad)
+            finally:
+                self.residual_dtype = rd
         if unpad:
             return self._forward_packed(input_ids, attention_mask)
         hid = self.last_hidden_state(input_ids, attention_mask)
@@ -611,10 +619,16 @@ class ClipVisualEncoder(_EncoderBase):
         """frames (B,F,3,224,224) or (B,3,224,224) -> (B,512) features.  strict: as BertTextEncoder.forward."""
         if frames.dim() == 4:
             frames = frames[:, None]
-        if strict and self.fold_ln:
-            out = self.forward(frames)
-            if not self.check_fold():
-                return out
+        if strict:      # (fp32 residual stream for offline feature building: see BertTextEncoder.forward)
+            rd, self.residual_dtype = self.residual_dtype, "fp32"
+            try:
+                if self.fold_ln:
+                    out = self.forward(frames)
+                    if not self.check_fold():
+                        return out
+                return self.forward(frames)
+            finally:
+                self.residual_dtype = rd
         B, Fr = frames.shape[:2]
         e, b = self._run(frames)
         L.check(L.lib().ufnd_l2norm_frames(e.data_ptr(), b["feat"].data_ptr(), B, Fr, self.proj, L.stream_ptr(self.device)),

@@ -128,8 +128,22 @@ class EncoderPipeline:
         while self._guard_pending and self._guard_pending[0][0].query():
             _, slot, which = self._guard_pending.pop(0)
             enc = self.text_encoder if which == "text" else self.visual_encoder
-            if enc is not None and enc.fold_ln and enc.check_fold(reset=False, ratio=float(self._guard_host[slot].max())):      # (the device slots are running maxima: never reset here)
+            ratio = self._guard_host[slot]
+            # (a NaN / Inf statistic never wins the kernels' fmaxf: a non-finite slot -- or any slot a non-finite row left untouched while
+            #  its output is garbage -- is a trip too; the device slots are running maxima: never reset here)
+            r = float("inf") if not bool(torch.isfinite(ratio).all()) else float(ratio.max())
+            if enc is not None and enc.fold_ln and enc.check_fold(reset=False, ratio=r):
                 self.stats["fold_trips"] += 1
+                # passes of this encoder that were already enqueued folded when the trip was seen consumed the same kind of rows:
+                # counted, so that a run can tell "switched in time" from "trained on folded outliers for a while"
+                late = sum(1 for _, _, w in self._guard_pending if w == which)
+                self.stats["fold_passes_after_trip"] = self.stats.get("fold_passes_after_trip", 0) + late
+                # the encoder's captured graphs may still be replaying on its stream: wait for its newest recorded pass before
+                # the CUDAGraph objects go away
+                for ev, _, w in reversed(self._guard_pending):
+                    if w == which:
+                        ev.synchronize()
+                        break
                 self.drop_graphs(which)
 
     def _guard_record(self, which: str, enc, stream) -> None:

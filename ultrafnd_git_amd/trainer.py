@@ -185,6 +185,11 @@ class ForensicTrainer:
             self._enc_dirty = False
         self.reducer = GradReducer(self.arena.ensure_grad(), group=self.comm, bounds=bounds,
                                    force=force_exchange, payload=cfg.grad_payload, algorithm=cfg.grad_exchange)
+        if self.text_bp is not None and self.world > 1:
+            # the encoders are built by the caller, before this constructor seeds anything: replicas may start from different RNG
+            # states.  They only ever exchange gradients, so unequal masters would silently stay unequal.
+            broadcast_from_rank0(self.arena.data, self.comm)
+            self._sync_encoder_operands()
         self.optim = FusedAdamW(self.arena, lr=cfg.lr, weight_decay=cfg.weight_decay,
                                 max_norm=cfg.grad_clip if cfg.grad_clip and cfg.grad_clip > 0 else 0.0,
                                 seed=cfg.seed + 1000 * self.rank, grad_scale=self.reducer.grad_scale)
@@ -500,11 +505,7 @@ class ForensicTrainer:
                 self.best_val_auc = val_auc
                 self.no_improve = 0
                 # rank 0 writes the file atomically; every rank leaves save_checkpoint only when it is complete
-                save_checkpoint({"fusion": {k: v.cpu() for k, v in self.fusion.state_dict().items()},
-                                 "clf": {k: v.cpu() for k, v in self.clf.state_dict().items()},
-                                 "gnn": ({k: v.cpu() for k, v in self.gnn_model.state_dict().items()} if self.gnn_model is not None
-                                         else self.gnn.state_dict() if self.gnn is not None else None), "cfg": dict(self.cfg.__dict__)},
-                                self.ckpt_path, self.comm)
+                save_checkpoint(self._checkpoint_state(), self.ckpt_path, self.comm)
                 if self.rank == 0:
                     print(f"  ↳ saved best checkpoint to {self.ckpt_path} (val_auc={self.best_val_auc:.3f})")
             else:
@@ -515,16 +516,50 @@ class ForensicTrainer:
                     break
         return self.best_val_auc
 
-    def test(self) -> Dict[str, float]:
-        # rank 0 reads the checkpoint; every rank then continues with rank 0's parameters (one broadcast of the arena),
-        # so no rank ever evaluates its shard with a stale or half-written file
+    def _checkpoint_state(self) -> dict:
+        """The `best.pt` dict (forensic_trainer.py:355-360): fusion, clf, gnn, cfg -- and, when the encoders are trained with the
+        head (train_encoders), their masters under keys of their own: the head of the best epoch is only meaningful together with
+        the encoders of that epoch."""
+        st = {"fusion": {k: v.cpu() for k, v in self.fusion.state_dict().items()},
+              "clf": {k: v.cpu() for k, v in self.clf.state_dict().items()},
+              "gnn": ({k: v.cpu() for k, v in self.gnn_model.state_dict().items()} if self.gnn_model is not None
+                      else self.gnn.state_dict() if self.gnn is not None else None), "cfg": dict(self.cfg.__dict__)}
+        if self.text_bp is not None:
+            st["text_encoder"] = {k: v.cpu() for k, v in self.text_encoder.state_dict().items()}
+            st["visual_encoder"] = {k: v.cpu() for k, v in self.visual_encoder.state_dict().items()}
+        return st
+
+    def _load_checkpoint(self) -> bool:
+        """Rank 0 reads best.pt (weights_only); every rank then continues with rank 0's parameters (one broadcast of the arena:
+        head and -- when they are trained -- encoder masters live in it).  Returns whether a file was read on rank 0."""
+        found = False
         if self.rank == 0 and os.path.exists(self.ckpt_path):
+            found = True
             ck = torch.load(self.ckpt_path, map_location="cpu", weights_only=True)
             self.fusion.load_state_dict(ck["fusion"])
             self.clf.load_state_dict(ck["clf"])
             if self.gnn_model is not None and ck.get("gnn") is not None:
                 self.gnn_model.load_state_dict(ck["gnn"])
+            if self.text_bp is not None and ck.get("text_encoder") is not None:      # (the masters are arena views: loaded in place)
+                self.text_encoder.load_state_dict(ck["text_encoder"])
+                self.visual_encoder.load_state_dict(ck["visual_encoder"])
         broadcast_from_rank0(self.arena.data, self.comm)
+        if self.text_bp is not None:      # every operand copy derived from the masters is stale now
+            self._sync_encoder_operands()
+        return found
+
+    def _sync_encoder_operands(self) -> None:
+        for enc in (self.text_encoder, self.visual_encoder):
+            enc._packed = None
+            enc.weights_version += 1
+        self.text_bp.refresh_operands()
+        self.vis_bp.refresh_operands()
+        self._enc_dirty = False
+
+    def test(self) -> Dict[str, float]:
+        # rank 0 reads the checkpoint; every rank then continues with rank 0's parameters (one broadcast of the arena),
+        # so no rank ever evaluates its shard with a stale or half-written file
+        self._load_checkpoint()
         self.fusion.eval()
         self.clf.eval()
         ts_loss, ts_metrics = self._epoch_loop(self.test_loader, "test")
