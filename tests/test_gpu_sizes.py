@@ -49,6 +49,11 @@ def test_tier_a_forward_backward_vs_oracle(B):
     print(f"B={B}: worst relative gradient error {worst:.2e}")
 
 
+# three criteria (max-abs, relative L2, 1 - cos), bounds = 2 x measured on MI355X (these two were 4e-3 max-abs only)
+CFG4_TEXT_BOUNDS = (4e-3, 3e-2, 3e-4)
+CFG5_VIS_BOUNDS = (4e-3, 3e-2, 3e-4)
+
+
 def _encoders(layers=2, vocab=1000):
     from oracle import encoders_ref as E
     from ultrafnd_git_amd.encoders import BertTextEncoder, ClipVisualEncoder
@@ -76,7 +81,8 @@ def test_config4_text_only_seq512_batch128():
     sub = tenc(ids[rows], mask[rows]).clone()
     assert torch.equal(sub, feat[rows]), "row independence must be exact: same per-row arithmetic order in any batch"
     ref = E.text_features(wt, ids[rows], mask[rows])
-    assert (sub.cpu() - ref).abs().max().item() <= 4e-3
+    from tests.helpers import assert_features_close
+    assert_features_close(sub.cpu(), ref, *CFG4_TEXT_BOUNDS, what="configs[3] geometry (2-layer encoder, L = 512, B = 128), sampled rows")
     from oracle import tier_a as O
     fus_sd, clf_sd = O.seeded_params(78)
     fusion, clf = CrossModalTransformer(), DeepTruthClassifier()
@@ -106,7 +112,8 @@ def test_config5_multiframe_8x224():
     feat = venc(frames).clone()
     assert (feat.norm(dim=1) - 1.0).abs().max().item() <= 1e-4
     ref = E.visual_features(wv, frames[:2])
-    assert (feat[:2].cpu() - ref).abs().max().item() <= 4e-3
+    from tests.helpers import assert_features_close
+    assert_features_close(feat[:2].cpu(), ref, *CFG5_VIS_BOUNDS, what="configs[4] shard (2-layer encoder, 8 frames, B = 8), samples 0, 1")
     # frame order does not matter (mean over frames); a single frame repeated equals that frame's feature
     perm = frames[:, torch.randperm(Fr, generator=torch.Generator().manual_seed(0))]
     assert (venc(perm) - feat).abs().max().item() <= 2e-6

@@ -66,8 +66,18 @@ class DeepTruthClassifier(ArenaModule):
         in_dim = int(cfg.get("input_dim", self.hidden))
         if in_dim != self.hidden:
             raise ValueError("input_dim must equal hidden_dim (the fusion head's output width)")
+        # The reference's YAML takes any value here (deep_truth_classifier.py:106-117); the HIP kernels are built for the ranges
+        # below (include/ultrafnd_hip.h, check_dims in csrc/tier_a.hip).  Refused at construction, naming the limit -- never at
+        # the first forward on the device, and never silently.
         if self.num_classes != 2:
-            raise ValueError("the HIP path implements the reference's binary head (num_classes=2)")
+            raise ValueError(f"classifier.yaml: num_classes={self.num_classes}: the HIP path implements the reference's binary head (num_classes == 2)")
+        if self.hidden not in (256, 512, 1024):
+            raise ValueError(f"classifier.yaml: hidden_dim={self.hidden}: the HIP kernels support hidden_dim in {{256, 512, 1024}}")
+        if not (1 <= self.node_depth <= 6 and 1 <= self.node_trees <= 16 and self.node_trees * self.node_depth <= 32):
+            raise ValueError(f"classifier.yaml: node_trees={self.node_trees}, node_depth={self.node_depth}: the HIP kernels support "
+                             "node_trees <= 16, node_depth <= 6 and node_trees x node_depth <= 32 (one lane per gate)")
+        if self.use_aux and self.aux_dim not in (0, 2, 4):
+            raise ValueError(f"classifier.yaml: aux_dim={self.aux_dim}: the HIP kernels support aux_dim in {{0, 2, 4}}")
         self.eff_aux = self.aux_dim if self.use_aux else 0
         self.pre = nn.Sequential(nn.Linear(in_dim + self.eff_aux, self.hidden), nn.GELU(), nn.Dropout(self.dropout),
                                  nn.Linear(self.hidden, self.hidden), nn.GELU(), nn.Dropout(self.dropout))

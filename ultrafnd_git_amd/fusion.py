@@ -35,7 +35,9 @@ class ForensicCoAttention(nn.Module):
         self.evidence_proj = nn.Sequential(nn.Linear(evidence_dim, hidden_dim), nn.GELU(), nn.Linear(hidden_dim, 1))
 
     def forward(self, x, y, evidence):  # pragma: no cover - fused into CrossModalTransformer
-        raise RuntimeError("ForensicCoAttention is evaluated inside CrossModalTransformer's fused HIP kernels")
+        raise RuntimeError("ForensicCoAttention.forward: this class is a parameter container here -- the three blocks are evaluated inside "
+                           "CrossModalTransformer's fused HIP kernels (one stacked (9H, H) GEMM + coattn_pairs); call the parent module "
+                           "(INTEGRATION.md section A lists this difference from cross_modal_transformer.py:39-55)")
 
 
 class _SemanticParams(nn.Module):
@@ -63,6 +65,8 @@ class CrossModalTransformer(ArenaModule):
         self.use_gnn = bool(cfg.get("use_gnn", True))
         self.gnn_dim = int(cfg.get("gnn_dim", 128))
         self.dtype = torch.float32
+        if self.hidden not in (256, 512, 1024):      # (the reference's YAML takes any width, cross_modal_transformer.py:87; the kernels do not)
+            raise ValueError(f"fusion.yaml: hidden_dim={self.hidden}: the HIP kernels support hidden_dim in {{256, 512, 1024}}")
         H = self.hidden
         # construction order == the reference's (:96-130) so the RNG stream matches
         self.text_proj = nn.Linear(768, H)
