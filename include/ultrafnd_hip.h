@@ -239,7 +239,15 @@ int ufnd_gemm_bf16(const void* A, const void* W, const float* bias, const float*
 /* Same, with an explicit tile configuration (the encoders pick tiles per compute-unit partition): tile_cfg < 0 =
  * automatic; otherwise the id of a tile built into this library (ufnd_gemm_bf16_tile_info; table in
  * csrc/gemm_bf16_kernel.hpp: block tile, wave grid, LDS ring slots of the A and W operands).  N must be a multiple
- * of the tile width; any other id is rejected with UFND_ERR_INVALID. */
+ * of the tile width; any other id is rejected with UFND_ERR_INVALID.
+ * UFND_GEMM_TILE_PERSISTENT (round 4) names the persistent, software-pipelined form (csrc/gemm_bf16_pp.hpp): one workgroup per
+ * compute unit walks 256 x 128 tiles with two accumulator sets -- the epilogue of a tile rides through the K loop of the
+ * next one, the LDS-DMA operand stream never drains -- for K = 768, M a multiple of 256, N a multiple of 128, bf16 output
+ * only (ufnd_gemm_bf16_ln: folded LayerNorm [+ activation], or the bf16 residual stream with out_stats; no fp32 residual /
+ * output); any other call that names it is refused.  Same bits as the table's tiles (tests/test_gpu_gemm_pp.py).  The
+ * automatic choice takes it for folded-LayerNorm calls with an activation once a workgroup gets two tiles (the FFN1 Linears
+ * of both encoders at encoder lookahead >= 2, and of configs[3]). */
+#define UFND_GEMM_TILE_PERSISTENT 64
 int ufnd_gemm_bf16_ex(const void* A, const void* W, const float* bias, const float* residual, void* out_bf16,
                       float* out_f32, int M, int N, int K, int lda, int ldw, int ldr, int ldo, int ldf, int act,
                       int tile_cfg, void* stream);
@@ -277,7 +285,7 @@ typedef struct ufnd_gemm_ln {
   int a_parts, r_parts;
   float a_eps, r_eps;
   int width;
-  int tile_cfg; /* < 0: automatic; otherwise a LayerNorm-aware tile id (ufnd_gemm_bf16_tile_info) */
+  int tile_cfg; /* < 0: automatic; otherwise a LayerNorm-aware tile id (ufnd_gemm_bf16_tile_info) or UFND_GEMM_TILE_PERSISTENT */
   /* bf16 residual stream (ABI v3): the residual operand as (M, ldrb) bf16 rows -- the rounding the producing GEMM already
    * wrote for its consumer -- instead of the fp32 `residual` argument (exclusive).  With it and out_f32 = NULL a residual
    * GEMM moves 2 + 2 B per element of the stream instead of 4 + 4 + 2; the stream then carries 8 significant bits per

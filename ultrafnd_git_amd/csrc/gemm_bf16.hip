@@ -4,7 +4,7 @@
 #include "gemm_bf16_kernel.hpp"
 
 // the persistent, software-pipelined form (gemm_bf16_pp.hpp), compiled in gemm_bf16_pp.hip
-#define UFND_GEMM_TILE_PP 64
+#define UFND_GEMM_TILE_PP UFND_GEMM_TILE_PERSISTENT
 int ufnd_pp_pick(const void* gemm_args);
 int ufnd_pp_launch(void* gemm_args, void* stream);
 

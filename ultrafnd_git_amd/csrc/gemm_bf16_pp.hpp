@@ -28,7 +28,7 @@
 #ifndef UFND_PP_WPE
 #define UFND_PP_WPE 2
 #endif
-#define UFND_GEMM_TILE_PP 64      // the id this form answers to in ufnd_gemm_ln.tile_cfg / ufnd_gemm_bf16_ex (not a table entry)
+#define UFND_GEMM_TILE_PP UFND_GEMM_TILE_PERSISTENT      // the id this form answers to in ufnd_gemm_ln.tile_cfg / ufnd_gemm_bf16_ex (include/ultrafnd_hip.h; not a table entry)
 
 namespace {
 namespace pp {

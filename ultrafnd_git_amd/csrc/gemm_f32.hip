@@ -749,6 +749,8 @@ int launch_tn(const TnProb* probs, int nprob, hipStream_t stream) {
       vec4 = false;
     a.p[i] = p;
   }
+  // (32 x 64 tiles -- VEC = 2, twice the waves, half the MFMA chain each -- were measured for the 32-row grouped launch in round 4:
+  //  head-only step 0.254-0.256 -> 0.264 ms; the 32 x 128 form stays)
   const int VEC = vec4 ? 4 : 2;
   int total = 0;
   for (int i = 0; i < nprob; ++i) {
