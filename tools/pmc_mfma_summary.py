@@ -30,7 +30,7 @@ for r in csv.DictReader(open(f)):
         dur[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 rows = []
 for k, v in agg.items():
-    if "gemm_bf16" not in k[0] and "attention" not in k[0]:
+    if "gemm_bf16" not in k[0] and "gemm_pp_kernel" not in k[0] and "attention" not in k[0]:
         continue
     m = {c: sum(x) / len(x) for c, x in v.items()}
     cyc = m["GRBM_GUI_ACTIVE"] / 8.0
@@ -44,10 +44,10 @@ with open(out, "w") as fo:
     tb = tc = 0.0
     for _, k, n, us, ghz, busy, util, mops, sqb, sqw in rows:
         fo.write(f"| {k[0]} | {k[1]} | {n} | {us:.2f} | {ghz:.2f} | {busy:.0f} | **{util:.3f}** | {mops:.0f} | {sqb:.0f} | {sqw:.0f} |\n")
-        if "gemm_bf16" in k[0]:
+        if "gemm_bf16" in k[0] or "gemm_pp_kernel" in k[0]:
             tb += busy * n
             tc += busy / util * n
-    fo.write(f"\nAll `gemm_bf16_kernel` launches, launch-weighted: MFMA utilisation **{tb / tc:.3f}** of the matrix pipes' cycles while a GEMM is running "
+    fo.write(f"\nAll `gemm_bf16_kernel` / `gemm_pp_kernel` launches, launch-weighted: MFMA utilisation **{tb / tc:.3f}** of the matrix pipes' cycles while a GEMM is running "
              "(counters serialise the streams: each launch has the chip to itself here).\n")
     fo.write("\nThe K loop itself issues MFMAs on 75-85 % of its cycles (in-kernel stamps: profiles/r03_gemm_stamps_g4.txt, earlier rounds' profiles/r0*_gemm_stamps*.txt); "
              "the launch-level figure is lower because prologue (first operands landing), epilogue (GELU, or residual + bf16 + statistics) and the tile counts "

@@ -28,7 +28,7 @@ agg = collections.defaultdict(list)
 for r in rows:
     key = (short(r["Kernel_Name"]), int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), r["Grid_Size_Y"], r["Grid_Size_Z"])
     agg[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-gem = [r for r in rows if "gemm_bf16" in r["Kernel_Name"]]
+gem = [r for r in rows if "gemm_bf16" in r["Kernel_Name"] or "gemm_pp_kernel" in r["Kernel_Name"]]
 pl = j["roofline"].get("per_launch")          # (absent in the --train-encoders line: its roofline is the whole step only)
 n_inst = 3 * j["roofline"].get("launches_per_encoder_pass", j["roofline"].get("launches_per_step", 0)) if pl else 0
 inst = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in gem[-n_inst:]] if n_inst else []
@@ -41,7 +41,7 @@ with open(f"profiles/{tag}_summary.md", "w") as f:
             f"**{j['value']} samples/s, {j['ms_per_step']} ms/step**, whole-step `roofline.frac` {j['roofline']['frac']}.\n\n")
     if pl:
         roc = sum(inst) / len(inst) / 1e3
-        f.write(f"Cross-check of the per-launch figure, both taken in THIS run: `gemm_bf16_kernel` durations in the instrumented sequential pass "
+        f.write(f"Cross-check of the per-launch figure, both taken in THIS run: `gemm_bf16_kernel` + `gemm_pp_kernel` durations in the instrumented sequential pass "
                 f"(the one bench.py times with HIP events): rocprofv3 {len(inst)} launches, average **{roc:.2f} us**; HIP events minus marker price in the "
                 f"same pass: **{pl['avg_launch_us']} us** (raw event interval {pl['avg_event_interval_us']} us, marker {pl['event_marker_us']} us) -- "
                 f"{abs(pl['avg_launch_us'] / roc - 1) * 100:.1f} % apart.  In the timed region (three concurrent streams, kernels share the CUs) rocprofv3 "
@@ -51,7 +51,7 @@ with open(f"profiles/{tag}_summary.md", "w") as f:
                 f"2.5 PFLOP/s (profiled clock); whole step {j['roofline']['flops_per_step'] / 1e9:.1f} GFLOP / {j['ms_per_step']} ms = "
                 f"{j['roofline']['flops_per_step'] / j['ms_per_step'] / 1e9:.0f} TFLOP/s = {j['roofline']['frac']}.\n\n")
     else:
-        f.write(f"`gemm_bf16_kernel` launches in the trace (forward and backward forms): {len(over)}, average {sum(over) / max(1, len(over)) / 1e3:.2f} us.\n\n")
+        f.write(f"`gemm_bf16_kernel` + `gemm_pp_kernel` launches in the trace (forward and backward forms): {len(over)}, average {sum(over) / max(1, len(over)) / 1e3:.2f} us.\n\n")
     if unprofiled:
         u = json.loads([l for l in open(unprofiled) if l.startswith('{"metric"')][-1])
         up = u["roofline"].get("per_launch")
