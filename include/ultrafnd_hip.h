@@ -154,6 +154,10 @@ int ufnd_fusion_backward(const ufnd_dims* d, const ufnd_fusion_params* p, const 
 #define UFND_BWD_ALL 0
 #define UFND_BWD_FUSE_MLP 1
 #define UFND_BWD_REST 2
+/* OR-ed into `phase` (and the `flags` of ufnd_classifier_backward_ex): run the backward WITHOUT the Linear layers' dW / db
+ * products -- every other gradient and the whole dX chain as usual.  The caller forms those products from gathered
+ * factors (ufnd_head_linear_grads_from_factors below); until then the Linear entries of `g` hold stale values. */
+#define UFND_BWD_NO_LINEAR_GRADS 16
 int ufnd_fusion_backward_phase(const ufnd_dims* d, const ufnd_fusion_params* p, const ufnd_fusion_params* g,
                                const float* text, const float* audio, const float* visual, const float* temporal,
                                const float* gnn, int B, int train, float* workspace, const float* d_fused,
@@ -177,6 +181,31 @@ int ufnd_classifier_forward(const ufnd_dims* d, const ufnd_clf_params* p, const 
 int ufnd_classifier_backward(const ufnd_dims* d, const ufnd_clf_params* p, const ufnd_clf_params* g, int B,
                              int train, float* workspace, const float* d_logits, float* d_fused, int ld_dfused,
                              const ufnd_step_state* state, void* stream, void* side_stream, int join);
+
+int ufnd_classifier_backward_ex(const ufnd_dims* d, const ufnd_clf_params* p, const ufnd_clf_params* g, int B,
+                                int train, float* workspace, const float* d_logits, float* d_fused, int ld_dfused,
+                                const ufnd_step_state* state, void* stream, void* side_stream, int join, int flags);
+
+/* ------------------------------------------------------------------------------------
+ * Factor form of the head's Linear gradients, for a data-parallel gradient exchange that moves FACTORS instead of
+ * gradients (the reference step is single-process: forensic_trainer.py:285-298; loss.backward() at :291 is what is
+ * being distributed).  All 13 Linear layers of the head (fuse_mlp.0/.3, the nine stacked q/k/v, the five input
+ * projections, pre.0/.3: 50.9 of the 51.0 MB of gradient) have dW = dY^T X and db = column sums of dY over the batch
+ * rows, so the sum over ranks is the same product over ALL ranks' rows:
+ *   1. backward with UFND_BWD_NO_LINEAR_GRADS (both modules);
+ *   2. ufnd_head_pack_factors: the rank's dY / X panels out of the two workspaces and the step's inputs into ONE
+ *      contiguous pack of ufnd_head_factor_floats(d, B) floats (one launch; 2.5 MB at B = 32, hidden 512);
+ *   3. all-gather the packs (rank r's pack at packs + r * rank_stride);
+ *   4. ufnd_head_linear_grads_from_factors: the SUMMED dW / db of every Linear over ranks * B rows, written into the
+ *      gradient tables in one grouped launch (fp32 MFMA; rows in rank order, so every rank computes the same bits).
+ * The remaining gradients (gates, thresholds, leaves, bypass, evidence_proj: 21 k floats) are summed by an ordinary
+ * all-reduce.  ranks == 1 reproduces the plain backward's dW / db bit for bit.
+ * ---------------------------------------------------------------------------------- */
+size_t ufnd_head_factor_floats(const ufnd_dims* d, int B);
+int ufnd_head_pack_factors(const ufnd_dims* d, const float* text, const float* audio, const float* visual, const float* temporal,
+                           const float* gnn, int B, float* fusion_workspace, float* clf_workspace, float* pack, void* stream);
+int ufnd_head_linear_grads_from_factors(const ufnd_dims* d, const ufnd_fusion_params* fusion_grads, const ufnd_clf_params* clf_grads,
+                                        const float* packs, size_t rank_stride, int ranks, int B, void* stream);
 
 /* F.cross_entropy(logits, y), mean reduction, + its gradient (forensic_trainer.py:287).
  * labels int64 (B).  loss_rows (B) or NULL; d_logits (B,2) = (softmax - onehot)/B or NULL.

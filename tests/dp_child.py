@@ -5,6 +5,9 @@
                   bit-identical to the same steps without any exchange (a one-rank sum is the identity).
   --mode variants world 1, RCCL, forced exchange: the bf16-payload and the reduce-scatter + all-gather forms of the exchange run
                   on the device (a one-rank sum: fp32 payloads leave the gradient unchanged, the bf16 payload rounds it once).
+  --mode factors2 two ranks sharing cuda:0 over gloo (host-staged like world2): the FACTOR form of the exchange (TrainConfig.grad_exchange =
+                  "factors": all-gathered dY / X panels, the summed Linear gradients formed locally) against the all-reduce form and the
+                  single-process full-batch step.
   --mode world2   two ranks sharing cuda:0 over gloo (device tensors staged through host memory by tests/host_staged.py's
                   Collectives subclass -- the product has no such path, its exchange is RCCL): sharded batches + summed gradients + 1/world == the single-process
                   full-batch step; then fit() / test() with sharded loaders, gathered metrics, the rank-0 checkpoint.
@@ -209,6 +212,60 @@ def world2(out_dir):
     dist.destroy_process_group()
 
 
+def factors2(out_dir):
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    B = 16                                           # global batch; every rank takes B / world rows
+    batches = dict_batches(B, 3, 23)
+    ref = None
+    if rank == 0:                                    # single-process full-batch reference, BEFORE the group exists
+        torch.manual_seed(5)
+        tr0 = make_trainer(os.path.join(out_dir, "ref"), B, use_graph=False)
+        tr0.fusion.dropout = tr0.clf.dropout = tr0.clf.node_dropout = 0.0
+        tr0.head.step_bufs.clear()
+        tr0.fusion.train(); tr0.clf.train()
+        for b in batches:
+            tr0.train_step(b)
+        ref = (tr0.arena.data.clone(), tr0.arena.grad.clone(), float(tr0.optim.state.read().grad_norm))
+        del tr0
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from host_staged import HostStagedCollectives
+    got = {}
+    for tag, kw, graph in (("all_reduce", {}, True), ("factors", dict(grad_exchange="factors"), True), ("factors_eager", dict(grad_exchange="factors"), False)):
+        comm = HostStagedCollectives()
+        torch.manual_seed(5)
+        tr = make_trainer(os.path.join(out_dir, tag), B // world, use_graph=graph, group=comm, **kw)
+        assert tr.world == world and tr.reducer.active
+        assert (type(tr.reducer).__name__ == "FactorExchange") == tag.startswith("factors")
+        tr.fusion.dropout = tr.clf.dropout = tr.clf.node_dropout = 0.0
+        tr.head.step_bufs.clear()
+        tr.fusion.train(); tr.clf.train()
+        for b in batches:
+            tr.train_step({k: v[rank::world].contiguous() for k, v in b.items()})
+        torch.cuda.synchronize()
+        got[tag] = (tr.arena.data.clone(), tr.arena.grad.clone(), float(tr.optim.state.read().grad_norm), tr.reducer.wire_bytes(),
+                    [list(r) for r in getattr(tr.reducer, "small_ranges", [])], tr.arena.n_grad)
+    res = {}
+    rel = lambda a, b: float(((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item())
+    # the factor form sums a dW element over world x B rows in one chain, the all-reduce adds per-rank chains: fp32 summation order only
+    res["grad_rel_vs_all_reduce"] = rel(got["factors"][1], got["all_reduce"][1])
+    res["param_rel_vs_all_reduce"] = rel(got["factors"][0], got["all_reduce"][0])
+    res["graph_equals_eager"] = bool(torch.equal(got["factors"][0], got["factors_eager"][0]) and torch.equal(got["factors"][1], got["factors_eager"][1]))
+    res["wire_bytes"] = {k: v[3] for k, v in got.items()}
+    res["small_ranges"], res["n_grad"] = got["factors"][4], got["factors"][5]
+    mine = got["factors"][0].cpu()
+    other = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(other, mine)
+    res["ranks_agree"] = bool(all(torch.equal(o, other[0]) for o in other))
+    if rank == 0:
+        # the summed gradient of the two half-batch ranks is 2 x the full-batch mean gradient (grad_scale = 1 / world applies later)
+        res["grad_rel_vs_full_batch"] = rel(got["factors"][1] * 0.5, ref[1])
+        res["param_max_abs_err"] = (got["factors"][0] - ref[0]).abs().max().item()
+        res["param_scale"] = ref[0].abs().max().item()
+        res["grad_norm"], res["grad_norm_ref"] = got["factors"][2], ref[2]
+        print(json.dumps(res))
+    dist.destroy_process_group()
+
+
 def variants(out_dir):
     """The exchange variants on the device (RCCL, one rank): every form must run inside the step (graphs, two buckets, overlap),
     fp32 payloads must not change a bit of a one-rank sum, the bf16 payload must equal one bf16 rounding of the gradient."""
@@ -217,7 +274,7 @@ def variants(out_dir):
     res, B, arenas = {}, 16, {}
     for tag, kw in (("plain", None), ("ar_fp32", dict(grad_payload="fp32", grad_exchange="all_reduce")),
                     ("rsag_fp32", dict(grad_payload="fp32", grad_exchange="rs_ag")), ("ar_bf16", dict(grad_payload="bf16", grad_exchange="all_reduce")),
-                    ("rsag_bf16", dict(grad_payload="bf16", grad_exchange="rs_ag"))):
+                    ("rsag_bf16", dict(grad_payload="bf16", grad_exchange="rs_ag")), ("factors", dict(grad_exchange="factors"))):
         torch.manual_seed(5)
         tr = make_trainer(out_dir, B, use_graph=True, force_exchange=kw is not None, **(kw or {}))
         tr.fusion.train(); tr.clf.train()
@@ -228,6 +285,8 @@ def variants(out_dir):
         res[tag + "_wire_MB"] = round(tr.reducer.wire_bytes() / 1e6, 2)
     ref = arenas["plain"]
     res["fp32_forms_bit_identical"] = bool(torch.equal(arenas["ar_fp32"][0], ref[0]) and torch.equal(arenas["rsag_fp32"][0], ref[0]))
+    # the factor form with one rank forms every Linear gradient from its own pack: the same rows in the same order -- no bit changes
+    res["factors_bit_identical"] = bool(torch.equal(arenas["factors"][0], ref[0]) and torch.equal(arenas["factors"][1], ref[1]))
     res["bf16_forms_agree"] = bool(torch.equal(arenas["ar_bf16"][0], arenas["rsag_bf16"][0]))
     g = arenas["ar_bf16"][1]
     res["bf16_grad_is_bf16_valued"] = bool(torch.equal(g, g.to(torch.bfloat16).float()))
@@ -243,4 +302,4 @@ if __name__ == "__main__":
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     torch.cuda.set_device(0)
-    {"force1": force1, "world2": world2, "variants": variants}[a.mode](a.out)
+    {"force1": force1, "world2": world2, "variants": variants, "factors2": factors2}[a.mode](a.out)

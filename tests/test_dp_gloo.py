@@ -168,3 +168,127 @@ def test_shard_indices_partition_and_padding():
     perm = torch.randperm(9, generator=torch.Generator().manual_seed(0))
     a, b = shard_indices(9, 2, 0, perm), shard_indices(9, 2, 1, perm)
     assert a.tolist() == perm.tolist()[0::2] + [] and b.tolist() == (perm.tolist() + perm.tolist()[:1])[1::2]
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Factor exchange (dp.FactorExchange): the exchange logic on CPU tensors, world 2.  The product forms the Linear gradients with
+# ufnd_head_linear_grads_from_factors (GPU: tests/test_gpu_dp.py::test_factor_exchange_two_ranks_on_one_gpu); here the test supplies
+# `pack` / `form` for a toy two-Linear head, so what is checked is the class: which ranges are all-reduced, the gathered layout
+# (rank r's pack at r * stride), the call order, wire bytes, and equality with the all-reduce within fp32 summation order.
+# ------------------------------------------------------------------------------------------------------------------------
+def _factor_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ultrafnd_git_amd.arena import FlatArena
+        from ultrafnd_git_amd.dp import FactorExchange, GradReducer
+        torch.set_num_threads(2)
+        B, dims = 6, ((40, 24), (16, 72))                      # rows per rank; (N, K) of the two Linear layers
+        g = torch.Generator().manual_seed(100 + rank)
+        fac = [(torch.randn(B, n, generator=g), torch.randn(B, k, generator=g)) for n, k in dims]
+        small = {"s0": torch.randn(37, generator=g), "s1": torch.randn(5, generator=g), "enc": torch.randn(300, generator=g)}
+        groups = [[("w0", dims[0]), ("b0", (dims[0][0],))], [("s0", (37,))], [("w1", dims[1])], [("b1", (dims[1][0],))], [("s1", (5,))], [("enc", (300,))]]
+        arena = FlatArena(groups, [], torch.device("cpu"))
+        arena.ensure_grad()
+
+        def local_grads():
+            arena.grad.zero_()
+            for i, (dy, x) in enumerate(fac):
+                arena.grad_view(f"w{i}").copy_(dy.t() @ x)
+                arena.grad_view(f"b{i}").copy_(dy.sum(0))
+            for k, v in small.items():
+                arena.grad_view(k).copy_(v)
+        # all-reduce form (three buckets: [w0 b0 s0 | w1 b1 s1 | enc])
+        bounds = [arena.offsets["w1"][0], arena.offsets["enc"][0]]
+        local_grads()
+        ar = GradReducer(arena.grad, bounds=bounds)
+        ar.start(0); ar.start(1); ar.start(2); ar.finish()
+        want = arena.grad.clone()
+        # factor form: the Linear ranges run to the next tensor's offset (over the alignment gap), as the trainer builds them
+        order = sorted(arena.grad_keys, key=lambda k: arena.offsets[k][0])
+        lin = []
+        for i, k in enumerate(order):
+            if k[0] in "wb":
+                lo, hi = arena.offsets[k][0], (arena.offsets[order[i + 1]][0] if i + 1 < len(order) else arena.n_grad)
+                if lin and lin[-1][1] == lo:
+                    lin[-1] = (lin[-1][0], hi)
+                else:
+                    lin.append((lo, hi))
+        local_grads()
+        for i in range(2):                                     # (the backward ran WITHOUT the Linear products: stale values there)
+            arena.grad_view(f"w{i}").fill_(float("nan")); arena.grad_view(f"b{i}").fill_(float("nan"))
+        fx = FactorExchange(arena.grad, bounds=bounds, linear_ranges=lin)
+        assert fx.active and fx.factors and fx.head_end == arena.offsets["enc"][0]
+        covered = sorted(fx.small_ranges + fx.linear_ranges)
+        assert covered[0][0] == 0 and covered[-1][1] == fx.head_end and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+        pack = torch.cat([t.reshape(-1) for pair in fac for t in pair] + [torch.zeros(3)])       # (+ padding a real pack may carry)
+        calls = []
+
+        def form(packs, stride, ranks):
+            calls.append((stride, ranks))
+            assert stride == pack.numel() and ranks == world and packs.numel() == stride * ranks
+            off = 0
+            for i, (n, k) in enumerate(dims):
+                dy = torch.cat([packs[r * stride + off:r * stride + off + B * n].view(B, n) for r in range(ranks)])
+                off += B * n
+                x = torch.cat([packs[r * stride + off:r * stride + off + B * k].view(B, k) for r in range(ranks)])
+                off += B * k
+                arena.grad_view(f"w{i}").copy_(dy.t() @ x)
+                arena.grad_view(f"b{i}").copy_(dy.sum(0))
+        fx.start(0); fx.start(1)                               # (the head's buckets: nothing to start -- start_factors replaces them)
+        assert not fx._pending
+        fx.start_factors(pack, form)
+        fx.start(2)                                            # the encoder bucket keeps the all-reduce
+        assert not calls                                       # (the gradients are formed at finish(), behind the gather)
+        fx.finish()
+        got = arena.grad
+        res = {"calls": calls, "n_small": len(fx.small_ranges), "wire": fx.wire_bytes(), "ar_wire": ar.wire_bytes(),
+               "pack_bytes": pack.numel() * 4, "small_floats": sum(b - a for a, b in fx.small_ranges)}
+        res["finite"] = bool(torch.isfinite(got).all())
+        lin_mask = torch.zeros_like(got, dtype=torch.bool)
+        for a, b in fx.linear_ranges:
+            lin_mask[a:b] = True
+        res["small_bit_equal"] = bool(torch.equal(got[~lin_mask], want[~lin_mask]))
+        res["linear_rel"] = float(((got[lin_mask] - want[lin_mask]).abs().max() / want[lin_mask].abs().max()).item())
+        both = [torch.empty_like(got) for _ in range(world)]
+        dist.all_gather(both, got.clone())
+        res["ranks_bit_equal"] = bool(torch.equal(both[0], both[1]))
+        if rank == 0:
+            q.put(("ok", res))
+    except Exception as e:  # pragma: no cover
+        if rank == 0:
+            q.put(("err", repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_factor_exchange_equals_allreduce_within_summation_order():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_factor_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    status, res = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    assert status == "ok", res
+    assert res["calls"] == [[res["pack_bytes"] // 4, 2]] or res["calls"] == [(res["pack_bytes"] // 4, 2)]
+    assert res["finite"] and res["small_bit_equal"] and res["ranks_bit_equal"], res
+    assert res["linear_rel"] <= 2e-6, res                      # one chain over 2 x 6 rows against two chains of 6 added
+    assert res["n_small"] == 2 and res["small_floats"] < 200   # [s0 + its gap], [s1 + its gap]
+    assert res["wire"] == res["pack_bytes"] + 4 * (res["small_floats"] + 300 + 20)      # pack + small ranges + the encoder bucket (300 floats + gap to 320)
+    assert res["wire"] < res["ar_wire"]
+
+
+def test_complement_of_ranges():
+    from ultrafnd_git_amd.dp import _complement
+    assert _complement([(0, 10), (10, 30), (50, 60)], 0, 100) == [(30, 50), (60, 100)]
+    assert _complement([], 0, 7) == [(0, 7)]
+    assert _complement([(0, 7)], 0, 7) == []
+    with pytest.raises(ValueError):
+        _complement([(0, 10), (5, 12)], 0, 100)
+    with pytest.raises(ValueError):
+        _complement([(90, 110)], 0, 100)

@@ -61,3 +61,23 @@ def test_exchange_variants_run_on_the_device(launch_job, tmp_path):
     assert res["fp32_forms_bit_identical"] and res["bf16_forms_agree"] and res["bf16_grad_is_bf16_valued"], res
     assert res["ar_bf16_wire_MB"] * 2 == pytest.approx(res["ar_fp32_wire_MB"], rel=1e-3)
     assert 0.0 < res["bf16_param_max_rel"] < 1e-3, res
+    # factor exchange at world 1 (RCCL all-gather of one pack, the Linear gradients formed from it): no bit changes; 2.5 MB + the small ranges
+    assert res["factors_bit_identical"], res
+    assert res["factors_wire_MB"] * 15 < res["ar_fp32_wire_MB"], res
+
+
+def test_factor_exchange_two_ranks_on_one_gpu(launch_job, tmp_path):
+    """TrainConfig.grad_exchange="factors" with two ranks sharing the GPU (gloo, host-staged -- not a product path): every rank all-gathers
+    its dY / X panels and forms the summed Linear gradients over both ranks' rows in one launch (ufnd_head_linear_grads_from_factors); the
+    other 21 k gradient floats are all-reduced.  Against the all-reduce form of the same three steps: equal within fp32 summation order
+    (one chain over 2 x 8 rows instead of two chains of 8 added); against the single-process full-batch step: as the all-reduce form is;
+    both ranks end bit-identical; the captured and the eager step agree bit for bit."""
+    res = _run(launch_job, 2, "factors2", tmp_path, {})
+    assert res["ranks_agree"] and res["graph_equals_eager"], res
+    assert res["grad_rel_vs_all_reduce"] <= 2e-6 and res["param_rel_vs_all_reduce"] <= 2e-6, res
+    assert res["grad_rel_vs_full_batch"] <= 2e-5, res
+    assert res["param_max_abs_err"] <= 2e-5 * max(1.0, res["param_scale"]), res
+    assert abs(res["grad_norm"] - res["grad_norm_ref"]) <= 1e-4 * max(1.0, res["grad_norm_ref"]), res
+    small = sum(hi - lo for lo, hi in res["small_ranges"])
+    assert 15_000 < small < 40_000 and len(res["small_ranges"]) <= 4, res          # gates / thresholds / leaves / bypass + evidence_proj
+    assert res["wire_bytes"]["factors"] * 15 < res["wire_bytes"]["all_reduce"], res

@@ -77,6 +77,7 @@ class GemmLn(C.Structure):
 
 STEP_STATE_BYTES = C.sizeof(StepState)
 BWD_ALL, BWD_FUSE_MLP, BWD_REST = 0, 1, 2
+BWD_NO_LINEAR_GRADS = 16          # OR-ed into the phase / flags: the factor form of the gradient exchange (dp.FactorExchange)
 ABI_VERSION = 4
 FOLD_GUARD_SLOTS = 1024      # UFND_FOLD_GUARD_SLOTS
 
@@ -102,6 +103,15 @@ def _declare(lib: C.CDLL) -> None:
     lib.ufnd_classifier_forward.argtypes = [C.POINTER(Dims), C.POINTER(ClfParams), P, I, P, I, I, P, P, P, P, P]
     lib.ufnd_classifier_backward.argtypes = [C.POINTER(Dims), C.POINTER(ClfParams), C.POINTER(ClfParams), I, I, P, P, P,
                                              I, P, P, P, I]
+    lib.ufnd_classifier_backward_ex.argtypes = [C.POINTER(Dims), C.POINTER(ClfParams), C.POINTER(ClfParams), I, I, P, P, P,
+                                                I, P, P, P, I, I]
+    lib.ufnd_classifier_backward_ex.restype = I
+    lib.ufnd_head_factor_floats.argtypes = [C.POINTER(Dims), I]
+    lib.ufnd_head_factor_floats.restype = S
+    lib.ufnd_head_pack_factors.argtypes = [C.POINTER(Dims), P, P, P, P, P, I, P, P, P, P]
+    lib.ufnd_head_pack_factors.restype = I
+    lib.ufnd_head_linear_grads_from_factors.argtypes = [C.POINTER(Dims), C.POINTER(FusionParams), C.POINTER(ClfParams), P, S, I, I, P]
+    lib.ufnd_head_linear_grads_from_factors.restype = I
     lib.ufnd_softmax_ce.argtypes = [P, P, I, P, P, P, P]
     lib.ufnd_softmax_ce_weighted.argtypes = [P, P, I, C.c_float, C.c_float, C.c_float, P, P, P, P]
     lib.ufnd_softmax_ce_weighted.restype = I

@@ -482,7 +482,9 @@ struct TnArgs {
 // partial tiles meet in LDS and are added in wave order; wave w stores accumulator registers 4w..4w+3.  At B = 256 the
 // one-wave form is a chain of 8 load-then-MFMA passes with about one wave per SIMD to hide them behind (139 us for the
 // grouped launch, 72 us for the classifier's 272 tiles); this form has 4 x the waves and a quarter of the chain.
-template <int VEC, int MSPLIT = 0>
+// SEG = 1: the batch rows come in segments (TnProb::seg_rows; the factor form of the data-parallel exchange) -- its own
+// instantiation, so that the one-panel kernels keep their code.
+template <int VEC, int MSPLIT = 0, int SEG = 0>
 __global__ __launch_bounds__(256) void tn_kernel(const TnArgs args) {
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
   const int tile = MSPLIT ? (int)blockIdx.x : blockIdx.x * 4 + w;
@@ -521,9 +523,15 @@ __global__ __launch_bounds__(256) void tn_kernel(const TnArgs args) {
       for (int e = 0; e < 4; ++e) {
         const int m = mb + 8 * u + 4 * h + e;
         const bool ok = m < m_hi;
-        a[u][e] = ok ? dycol[(size_t)m * P.lddy] : 0.0f;
+        size_t oy = (size_t)m * P.lddy, ox = (size_t)m * P.ldx;
+        if constexpr (SEG) {
+          const int sg = m / P.seg_rows, r = m - sg * P.seg_rows;
+          oy = (size_t)sg * P.seg_dy + (size_t)r * P.lddy;
+          ox = (size_t)sg * P.seg_x + (size_t)r * P.ldx;
+        }
+        a[u][e] = ok ? dycol[oy] : 0.0f;
         if (ok && kok) {
-          const float* src = xcol + (size_t)m * P.ldx;
+          const float* src = xcol + ox;
           if constexpr (VEC == 4) {
             const f32x4 t = *reinterpret_cast<const f32x4*>(src);
             b[u][e][0] = t[0]; b[u][e][1] = t[1]; b[u][e][2] = t[2]; b[u][e][3] = t[3];
@@ -747,8 +755,14 @@ int launch_tn(const TnProb* probs, int nprob, hipStream_t stream) {
                  "tn[%d]: X/dW alignment", i);
     if (!(p.K % 4 == 0 && p.ldx % 4 == 0 && p.ldw % 4 == 0 && ufnd_aligned(p.X, 16) && ufnd_aligned(p.dW, 16)))
       vec4 = false;
+    UFND_REQUIRE(p.seg_rows >= 0 && (p.seg_rows == 0 || (p.M % p.seg_rows == 0 && p.seg_dy > 0 && p.seg_x > 0)), "tn[%d]: %d rows in segments of %d",
+                 i, p.M, p.seg_rows);
+    UFND_REQUIRE((p.seg_rows != 0) == (probs[0].seg_rows != 0), "tn[%d]: segmented and one-panel problems in one launch", i);
+    if (p.seg_rows && !(p.seg_x % 4 == 0)) vec4 = false;
+    UFND_REQUIRE(p.seg_rows == 0 || p.seg_x % 2 == 0, "tn[%d]: segment stride alignment", i);
     a.p[i] = p;
   }
+  const bool seg = probs[0].seg_rows != 0;
   // (32 x 64 tiles -- VEC = 2, twice the waves, half the MFMA chain each -- were measured for the 32-row grouped launch in round 4:
   //  head-only step 0.254-0.256 -> 0.264 ms; the 32 x 128 form stays)
   const int VEC = vec4 ? 4 : 2;
@@ -760,7 +774,15 @@ int launch_tn(const TnProb* probs, int nprob, hipStream_t stream) {
   a.begin[nprob] = total;
   int minM = a.p[0].M;
   for (int i = 1; i < nprob; ++i) minM = a.p[i].M < minM ? a.p[i].M : minM;
-  if (minM >= 128) {      // batch rows split over the four waves of a workgroup (one workgroup per tile)
+  if (seg) {              // gathered factors: the same two forms, rows addressed by segment
+    if (minM >= 128) {
+      if (vec4) hipLaunchKernelGGL((tn_kernel<4, 1, 1>), dim3(total), dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((tn_kernel<2, 1, 1>), dim3(total), dim3(256), 0, stream, a);
+    } else {
+      if (vec4) hipLaunchKernelGGL((tn_kernel<4, 0, 1>), dim3(ufnd_cdiv(total, 4)), dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((tn_kernel<2, 0, 1>), dim3(ufnd_cdiv(total, 4)), dim3(256), 0, stream, a);
+    }
+  } else if (minM >= 128) {      // batch rows split over the four waves of a workgroup (one workgroup per tile)
     if (vec4) hipLaunchKernelGGL((tn_kernel<4, 1>), dim3(total), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((tn_kernel<2, 1>), dim3(total), dim3(256), 0, stream, a);
   } else {

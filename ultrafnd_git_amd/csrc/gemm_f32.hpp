@@ -4,7 +4,7 @@
 #pragma once
 #include "common.hpp"
 
-#define UFND_GEMM_MAX_PROB 12
+#define UFND_GEMM_MAX_PROB 16
 
 // Y[m][n] = act(sum_k X[m][k] W[n][k] + bias[n])            (nn.Linear forward)
 struct NtProb {
@@ -43,5 +43,8 @@ struct TnProb {
   float* dW;          // (N, K) row stride ldw
   float* db;          // (N) or null
   int M, N, K, lddy, ldx, ldw;
+  // Batch rows in SEGMENTS (gathered data-parallel factors: rank r's rows live at dY + r * seg_dy, X + r * seg_x, seg_rows rows
+  // each, M = ranks x seg_rows); seg_rows == 0: one contiguous panel.
+  int seg_rows, seg_dy, seg_x;
 };
 int launch_tn(const TnProb* probs, int nprob, hipStream_t stream);

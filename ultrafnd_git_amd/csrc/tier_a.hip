@@ -1069,12 +1069,67 @@ extern "C" int ufnd_fusion_forward(const ufnd_dims* d, const ufnd_fusion_params*
   return UFND_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The Linear gradients of the head as dW = dY^T X problems over PANELS.  The backward passes its own workspace panels (one
+// contiguous panel of B rows each); the factor form of the data-parallel exchange passes every rank's packed panels
+// (ufnd_head_pack_factors) as row segments and forms the sum over ALL ranks' rows in one pass
+// (ufnd_head_linear_grads_from_factors): seg = {rows per rank, floats between two ranks' packs}.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct Seg { int rows, stride; };
+struct FusionFactors {
+  const float *dz2, *h1, *dz1, *cat, *dqkv;
+  const float *dproj[5], *x[5];      // gradients at the [text audio visual temporal gnn] projection outputs; the projections' inputs
+};
+FusionFactors fusion_factors(const FusionWs& w, size_t B, size_t H, const float* text, const float* audio, const float* visual,
+                             const float* temporal, const float* gnn) {
+  // (dtavu order is [t a v u] = [text audio visual temporal])
+  return FusionFactors{w.dz2, w.h1, w.dz1, w.cat, w.dqkv, {w.dtavu, w.dtavu + B * H, w.dtavu + 2 * B * H, w.dtavu + 3 * B * H, w.dg},
+                       {text, audio, visual, temporal, gnn}};
+}
+inline TnProb tn_prob(const float* dY, const float* X, float* dW, float* db, int M, int N, int K, int lddy, int ldx, int ldw, Seg sg) {
+  return TnProb{dY, X, dW, db, M, N, K, lddy, ldx, ldw, sg.rows, sg.stride, sg.stride};
+}
+// fuse_mlp.3 and fuse_mlp.0 (the 33.5 MB gradient): 2 problems
+int fusion_tn_fuse(const ufnd_dims& d, const FusionFactors& f, const ufnd_fusion_params* g, int M, TnProb* tn, Seg sg = Seg{0, 0}) {
+  const int H = d.hidden, CW = (d.gnn_dim > 0 ? 16 : 15) * H;      // (use_gnn: false: 15 slots; CAT keeps its 16H row stride)
+  tn[0] = tn_prob(f.dz2, f.h1, g->fuse3_w, g->fuse3_b, M, H, 2 * H, H, 2 * H, 2 * H, sg);
+  tn[1] = tn_prob(f.dz1, f.cat, g->fuse0_w, g->fuse0_b, M, 2 * H, CW, 2 * H, 16 * H, CW, sg);
+  return 2;
+}
+// stacked q/k/v (t -> [q_tv q_ta], v -> [k_tv v_tv q_vu], a -> [k_ta v_ta], u -> [k_vu v_vu]) and the projections: 4 + (5 | 4) problems
+int fusion_tn_rest(const ufnd_dims& d, const FusionFactors& f, const ufnd_fusion_params* g, int M, TnProb* tn, Seg sg = Seg{0, 0}) {
+  const int H = d.hidden;
+  const int src_slot[4] = {0, 2, 1, 3}, row0[4] = {0, 2, 5, 7}, nrows[4] = {2, 3, 2, 2};
+  int n = 0;
+  for (int i = 0; i < 4; ++i)
+    tn[n++] = tn_prob(f.dqkv + (size_t)row0[i] * H, f.cat + (size_t)src_slot[i] * H, g->qkv_w + (size_t)row0[i] * H * H,
+                      g->qkv_b + (size_t)row0[i] * H, M, nrows[i] * H, H, 9 * H, 16 * H, H, sg);
+  float* gw[5] = {g->text_w, g->audio_w, g->visual_w, g->temporal_w, g->gnn_w};
+  float* gb[5] = {g->text_b, g->audio_b, g->visual_b, g->temporal_b, g->gnn_b};
+  const int ks[5] = {d.text_dim, d.audio_dim, d.visual_dim, d.temporal_dim, d.gnn_dim};
+  for (int i = 0; i < (d.gnn_dim > 0 ? 5 : 4); ++i) tn[n++] = tn_prob(f.dproj[i], f.x[i], gw[i], gb[i], M, H, ks[i], H, ks[i], ks[i], sg);
+  return n;
+}
+// classifier pre.3 and pre.0 (over the full (hidden + aux) width): 2 problems
+struct ClfFactors { const float *dz4, *h3, *dz3, *xin; int ldx; };
+int clf_tn(const ufnd_dims& d, const ClfFactors& f, const ufnd_clf_params* g, int M, TnProb* tn, Seg sg = Seg{0, 0}) {
+  const int H = d.hidden;
+  tn[0] = tn_prob(f.dz4, f.h3, g->pre3_w, g->pre3_b, M, H, H, H, H, H, sg);
+  tn[1] = tn_prob(f.dz3, f.xin, g->pre0_w, g->pre0_b, M, H, H + d.aux_dim, H, f.ldx, H + d.aux_dim, sg);
+  return 2;
+}
+}  // namespace
+
 extern "C" int ufnd_fusion_backward_phase(const ufnd_dims* d, const ufnd_fusion_params* p, const ufnd_fusion_params* g,
                                           const float* text, const float* audio, const float* visual, const float* temporal,
                                           const float* gnn, int B, int train, float* workspace, const float* d_fused,
                                           int ld_dfused, const float* d_logits, const ufnd_step_state* state, void* stream_,
                                           void* side_stream_, int join, int phase) {
   TRY(check_dims(d, B));
+  // (factor form of the data-parallel exchange: the Linear dW / db products are left to ufnd_head_linear_grads_from_factors)
+  const bool linear = !(phase & UFND_BWD_NO_LINEAR_GRADS);
+  phase &= ~UFND_BWD_NO_LINEAR_GRADS;
   UFND_REQUIRE(phase == UFND_BWD_ALL || phase == UFND_BWD_FUSE_MLP || phase == UFND_BWD_REST, "fusion_backward: phase=%d", phase);
   const bool do_head = phase != UFND_BWD_REST, do_rest = phase != UFND_BWD_FUSE_MLP;
   UFND_REQUIRE(p && g && text && audio && visual && temporal && (gnn || (d && d->gnn_dim == 0)) && workspace && state, "fusion_backward: null argument");
@@ -1104,17 +1159,16 @@ extern "C" int ufnd_fusion_backward_phase(const ufnd_dims* d, const ufnd_fusion_
   UFND_CHECK_LAUNCH();
   // fuse_mlp.3: dW, db; dH1 -> dZ1 (epilogue applies gelu'(Z1) * mask)
   {
-    tn[ntn++] = TnProb{w.dz2, w.h1, g->fuse3_w, g->fuse3_b, B, H, 2 * H, H, 2 * H, 2 * H};
     NnProb n{w.dz2, p->fuse3_w, w.dz1, w.z1, nullptr, B, H, 2 * H, H, 2 * H, 2 * H, 2 * H, 0, drop, LAYER_FUSE0, 2 * H, 1};
     TRY(launch_nn(&n, 1, state, stream));
   }
   // fuse_mlp.0: dW (the 33.5 MB gradient), db; dCAT partials
   {
     const int CW = (d->gnn_dim > 0 ? 16 : 15) * H;      // (use_gnn: false: 15 slots; CAT / dCAT keep their 16H row stride)
-    tn[ntn++] = TnProb{w.dz1, w.cat, g->fuse0_w, g->fuse0_b, B, 2 * H, CW, 2 * H, 16 * H, CW};
+    ntn += fusion_tn_fuse(*d, fusion_factors(w, B, H, text, audio, visual, temporal, gnn), g, B, tn + ntn);
     NnProb n{w.dz1, p->fuse0_w, w.dcatp, nullptr, nullptr, B, 2 * H, CW, 2 * H, CW, 16 * H, 0, 0, 0.0f, 0, 0,
              NSPLIT_FUSE0};
-    if (phase == UFND_BWD_FUSE_MLP) {
+    if (phase == UFND_BWD_FUSE_MLP && linear) {
       // bucketed gradient exchange: the two fuse_mlp weight gradients (67 % of all gradient bytes) are written NOW,
       // ahead of the dCAT product, so that the caller can start reducing them while the rest of backward runs
       // (the grouped launch computes every problem independently: the same bits as the one-launch form)
@@ -1162,8 +1216,6 @@ extern "C" int ufnd_fusion_backward_phase(const ufnd_dims* d, const ufnd_fusion_
     const int src_slot[4] = {0, 2, 1, 3}, row0[4] = {0, 2, 5, 7}, nrows[4] = {2, 3, 2, 2};
     NnProb n[4];
     for (int i = 0; i < 4; ++i) {
-      tn[ntn++] = TnProb{w.dqkv + (size_t)row0[i] * H, w.cat + (size_t)src_slot[i] * H, g->qkv_w + (size_t)row0[i] * H * H,
-                    g->qkv_b + (size_t)row0[i] * H, B, nrows[i] * H, H, 9 * H, 16 * H, H};
       float* dst = w.dtavu + (size_t)src_slot[i] * B * H;  // dtavu order is [t a v u]
       n[i] = NnProb{w.dqkv + (size_t)row0[i] * H, p->qkv_w + (size_t)row0[i] * H * H, dst, nullptr, dst, B, nrows[i] * H,
                     H, 9 * H, H, H, 0, H, 0.0f, 0, 0, 1};
@@ -1171,16 +1223,9 @@ extern "C" int ufnd_fusion_backward_phase(const ufnd_dims* d, const ufnd_fusion_
     TRY(launch_nn(n, 4, state, stream));
     fj.fork(3);   // every dY of the module is ready
   }
-  // projections: dW, db (inputs are data: no dX)
-  {
-    const float* xs[5] = {text, audio, visual, temporal, gnn};
-    float* gw[5] = {g->text_w, g->audio_w, g->visual_w, g->temporal_w, g->gnn_w};
-    float* gb[5] = {g->text_b, g->audio_b, g->visual_b, g->temporal_b, g->gnn_b};
-    const int ks[5] = {d->text_dim, d->audio_dim, d->visual_dim, d->temporal_dim, d->gnn_dim};
-    const float* dys[5] = {w.dtavu, w.dtavu + (size_t)B * H, w.dtavu + (size_t)2 * B * H, w.dtavu + (size_t)3 * B * H, w.dg};
-    for (int i = 0; i < (d->gnn_dim > 0 ? 5 : 4); ++i) tn[ntn++] = TnProb{dys[i], xs[i], gw[i], gb[i], B, H, ks[i], H, ks[i], ks[i]};
-    TRY(launch_tn(tn, ntn, fj.dw()));
-  }
+  // stacked q/k/v and projections: dW, db (the projections' inputs are data: no dX)
+  ntn += fusion_tn_rest(*d, fusion_factors(w, B, H, text, audio, visual, temporal, gnn), g, B, tn + ntn);
+  if (linear) TRY(launch_tn(tn, ntn, fj.dw()));
   }  // do_rest
   if (join) fj.join(4);
   return UFND_OK;
@@ -1257,11 +1302,12 @@ extern "C" int ufnd_classifier_forward(const ufnd_dims* d, const ufnd_clf_params
   return UFND_OK;
 }
 
-extern "C" int ufnd_classifier_backward(const ufnd_dims* d, const ufnd_clf_params* p, const ufnd_clf_params* g, int B,
-                                        int train, float* workspace, const float* d_logits, float* d_fused,
-                                        int ld_dfused, const ufnd_step_state* state, void* stream_, void* side_stream_,
-                                        int join) {
+extern "C" int ufnd_classifier_backward_ex(const ufnd_dims* d, const ufnd_clf_params* p, const ufnd_clf_params* g, int B,
+                                           int train, float* workspace, const float* d_logits, float* d_fused,
+                                           int ld_dfused, const ufnd_step_state* state, void* stream_, void* side_stream_,
+                                           int join, int flags) {
   TRY(check_dims(d, B));
+  UFND_REQUIRE((flags & ~UFND_BWD_NO_LINEAR_GRADS) == 0, "classifier_backward: flags=%d", flags);
   UFND_REQUIRE(p && g && workspace && d_logits && d_fused && state, "classifier_backward: null argument");
   UFND_REQUIRE(ld_dfused % 4 == 0 && ufnd_aligned(d_fused, 16), "classifier_backward: d_fused alignment");
   hipStream_t stream = (hipStream_t)stream_;
@@ -1297,14 +1343,117 @@ extern "C" int ufnd_classifier_backward(const ufnd_dims* d, const ufnd_clf_param
   {  // both dW products of the module in one grouped launch (pre.0 over the full (hidden + aux) width), then pre.0's dX
      // over the fused columns only
     fj.fork(6);   // dz3 is ready
-    TnProb t[2] = {TnProb{w.dz4, w.h3, g->pre3_w, g->pre3_b, B, H, H, H, H, H},
-                   TnProb{w.dz3, w.xin, g->pre0_w, g->pre0_b, B, H, H + d->aux_dim, H, w.ldx, H + d->aux_dim}};
-    TRY(launch_tn(t, 2, fj.dw()));
+    TnProb t[2];
+    clf_tn(*d, ClfFactors{w.dz4, w.h3, w.dz3, w.xin, w.ldx}, g, B, t);
+    if (!(flags & UFND_BWD_NO_LINEAR_GRADS)) TRY(launch_tn(t, 2, fj.dw()));
     NnProb n{w.dz3, p->pre0_w, d_fused, nullptr, nullptr, B, H, H, H, H + d->aux_dim, ld_dfused, 0, 0, 0.0f, 0, 0, 1};
     TRY(launch_nn(&n, 1, state, stream));
   }
   if (join) fj.join(7);
   return UFND_OK;
+}
+
+extern "C" int ufnd_classifier_backward(const ufnd_dims* d, const ufnd_clf_params* p, const ufnd_clf_params* g, int B,
+                                        int train, float* workspace, const float* d_logits, float* d_fused,
+                                        int ld_dfused, const ufnd_step_state* state, void* stream_, void* side_stream_,
+                                        int join) {
+  return ufnd_classifier_backward_ex(d, p, g, B, train, workspace, d_logits, d_fused, ld_dfused, state, stream_, side_stream_, join, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Factor form of the head's Linear gradients (data parallel; the reference step is single-process, forensic_trainer.py:285-298).
+// Every large gradient of the head is dW = dY^T X over the batch rows, so the SUM over ranks of dW is dY_all^T X_all over all
+// ranks' rows: a rank packs its factor panels (2.5 MB at B = 32, hidden 512 -- against the 51 MB gradient), the packs are
+// all-gathered, and every rank forms the summed dW / db of all 13 Linears in ONE grouped launch over ranks x B rows.
+// Pack layout (floats, every panel on a 64-float boundary, B rows each):
+//   [dz2 H | h1 2H | dz1 2H | cat 16H | dqkv 9H | d_text_proj H | d_audio_proj H | d_visual_proj H | d_temporal_proj H | d_gnn_proj H |
+//    text | audio | visual | temporal | gnn | dz4 H | h3 H | dz3 H | xin (hidden + 4)]
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int FACTOR_PANELS = 19;
+struct FactorLayout {
+  size_t off[FACTOR_PANELS], n[FACTOR_PANELS];
+  size_t total;
+};
+FactorLayout factor_layout(const ufnd_dims& d, int B) {
+  const size_t H = d.hidden, b = B;
+  const size_t width[FACTOR_PANELS] = {H, 2 * H, 2 * H, 16 * H, 9 * H, H, H, H, H, H, (size_t)d.text_dim, (size_t)d.audio_dim, (size_t)d.visual_dim,
+                                       (size_t)d.temporal_dim, (size_t)d.gnn_dim, H, H, H, H + 4};
+  FactorLayout l;
+  size_t o = 0;
+  for (int i = 0; i < FACTOR_PANELS; ++i) {
+    l.off[i] = o;
+    l.n[i] = b * width[i];
+    o += al64(l.n[i]);
+  }
+  l.total = o;
+  return l;
+}
+struct CopyArgs {
+  const float* src[FACTOR_PANELS];
+  float* dst[FACTOR_PANELS];
+  unsigned n4[FACTOR_PANELS];      // 16-byte words
+};
+__global__ __launch_bounds__(256) void copy_panels_kernel(const CopyArgs a) {
+  const int it = blockIdx.y;
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  if (i < a.n4[it]) st4(a.dst[it] + 4 * (size_t)i, ld4(a.src[it] + 4 * (size_t)i));
+}
+}  // namespace
+
+extern "C" size_t ufnd_head_factor_floats(const ufnd_dims* d, int B) {
+  if (!d || B < 1) return 0;
+  return factor_layout(*d, B).total;
+}
+
+extern "C" int ufnd_head_pack_factors(const ufnd_dims* d, const float* text, const float* audio, const float* visual, const float* temporal,
+                                      const float* gnn, int B, float* fusion_workspace, float* clf_workspace, float* pack, void* stream_) {
+  TRY(check_dims(d, B));
+  UFND_REQUIRE(text && audio && visual && temporal && (gnn || d->gnn_dim == 0) && fusion_workspace && clf_workspace && pack, "head_pack_factors: null argument");
+  UFND_REQUIRE(d->text_dim % 4 == 0 && d->audio_dim % 4 == 0 && d->visual_dim % 4 == 0 && d->temporal_dim % 4 == 0 && d->gnn_dim % 4 == 0,
+               "head_pack_factors: input widths must be multiples of 4");
+  const FusionWs w = carve_fusion(*d, B, fusion_workspace);
+  const ClfWs c = carve_clf(*d, B, clf_workspace);
+  const FusionFactors f = fusion_factors(w, B, d->hidden, text, audio, visual, temporal, gnn);
+  const FactorLayout l = factor_layout(*d, B);
+  const float* src[FACTOR_PANELS] = {f.dz2, f.h1, f.dz1, f.cat, f.dqkv, f.dproj[0], f.dproj[1], f.dproj[2], f.dproj[3], f.dproj[4],
+                                     f.x[0], f.x[1], f.x[2], f.x[3], f.x[4], c.dz4, c.h3, c.dz3, c.xin};
+  CopyArgs a;
+  unsigned most = 0;
+  UFND_REQUIRE(ufnd_aligned(pack, 16), "head_pack_factors: pack alignment");
+  for (int i = 0; i < FACTOR_PANELS; ++i) {
+    const bool used = l.n[i] > 0 && src[i];
+    UFND_REQUIRE(!used || ufnd_aligned(src[i], 16), "head_pack_factors: panel %d is not 16-byte aligned", i);
+    a.src[i] = src[i];
+    a.dst[i] = pack + l.off[i];
+    a.n4[i] = used ? (unsigned)(l.n[i] / 4) : 0u;
+    most = a.n4[i] > most ? a.n4[i] : most;
+  }
+  hipLaunchKernelGGL(copy_panels_kernel, dim3(ufnd_cdiv((int)most, 256), FACTOR_PANELS), dim3(256), 0, (hipStream_t)stream_, a);
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}
+
+extern "C" int ufnd_head_linear_grads_from_factors(const ufnd_dims* d, const ufnd_fusion_params* fusion_grads, const ufnd_clf_params* clf_grads,
+                                                   const float* packs, size_t rank_stride, int ranks, int B, void* stream_) {
+  TRY(check_dims(d, B));
+  const FactorLayout l = factor_layout(*d, B);
+  UFND_REQUIRE(fusion_grads && clf_grads && packs && ranks >= 1, "head_linear_grads_from_factors: null argument");
+  UFND_REQUIRE(rank_stride >= l.total && rank_stride % 4 == 0 && rank_stride < (1u << 30) && ufnd_aligned(packs, 16),
+               "head_linear_grads_from_factors: rank stride %zu floats (a pack is %zu)", rank_stride, l.total);
+  UFND_REQUIRE((long long)ranks * B <= 4096, "head_linear_grads_from_factors: %d ranks x %d rows", ranks, B);
+  const float* q = packs;
+  const FusionFactors f{q + l.off[0], q + l.off[1], q + l.off[2], q + l.off[3], q + l.off[4],
+                        {q + l.off[5], q + l.off[6], q + l.off[7], q + l.off[8], q + l.off[9]},
+                        {q + l.off[10], q + l.off[11], q + l.off[12], q + l.off[13], q + l.off[14]}};
+  const ClfFactors c{q + l.off[15], q + l.off[16], q + l.off[17], q + l.off[18], d->hidden + 4};
+  const Seg sg{B, (int)rank_stride};
+  const int M = ranks * B;
+  TnProb tn[UFND_GEMM_MAX_PROB];
+  int n = fusion_tn_fuse(*d, f, fusion_grads, M, tn, sg);
+  n += fusion_tn_rest(*d, f, fusion_grads, M, tn + n, sg);
+  n += clf_tn(*d, c, clf_grads, M, tn + n, sg);
+  return launch_tn(tn, n, (hipStream_t)stream_);
 }
 
 extern "C" int ufnd_softmax_ce_weighted(const float* logits, const int64_t* labels, int B, float w0, float w1, float label_smoothing,

@@ -27,6 +27,13 @@ Exchange variants (`GradReducer(payload=, algorithm=)`, `TrainConfig.grad_payloa
   rank reduces 1/world of the bucket over all of its xGMI links, then gathers the reduced shards: the direct form of
   SURVEY.md 8e for a point-to-point fabric).
 
+  algorithm "factors" (`FactorExchange`, SURVEY.md 5: the head-only step is communication-bound -- a 51 MB ring all-reduce
+  against a 0.25 ms step) does not move the head's Linear gradients at all: every one of them is dW = dY^T X over the batch
+  rows, so each rank all-gathers its FACTOR panels (2.5 MB at B = 32) and forms the summed dW / db over all ranks' rows
+  locally, in rank order (ufnd_head_linear_grads_from_factors); the 21 k floats of other gradients are all-reduced as before.
+  `.grad` keeps its meaning (the sum over ranks), the wire carries 20 x fewer bytes per rank; the summation order of a dW
+  element differs from the all-reduce's (one chain over world x B rows instead of a sum of per-rank chains).
+
 Every collective goes through a `Collectives` object, which applies torch.distributed to tensors WHERE THEY LIVE: device
 tensors need a backend that reduces device memory (nccl).  There is no host staging in this package.
 """
@@ -200,6 +207,72 @@ class GradReducer:
         for w in self._pending:
             w.wait()
         self._pending = []
+
+
+def _complement(ranges: Sequence[Tuple[int, int]], lo: int, hi: int) -> List[Tuple[int, int]]:
+    """[lo, hi) minus the (sorted, merged) `ranges`."""
+    out, at = [], lo
+    for a, b in sorted(ranges):
+        if a < lo or b > hi or a < at:
+            raise ValueError(f"range ({a}, {b}) overlaps its predecessor or leaves [{lo}, {hi})")
+        if a > at:
+            out.append((at, a))
+        at = max(at, b)
+    if at < hi:
+        out.append((at, hi))
+    return out
+
+
+class FactorExchange(GradReducer):
+    """The head's gradient exchange in FACTOR form (module docstring, algorithm "factors").
+
+    `linear_ranges`: the [begin, end) float ranges of the gradient buffer that the factor product writes (the Linear layers'
+    weights and biases); everything else inside the head's buckets 0 and 1 -- [0, bounds[1]) or the whole buffer when there
+    are no further buckets -- is summed by plain all-reduces; buckets 2... (trainable encoders) keep the parent's all-reduce.
+    The owner of the step calls `start_factors(pack, form)` once its backward (run WITHOUT the Linear products) has packed the
+    rank's factor panels into `pack`: the packs are all-gathered, and at `finish()` `form(packs, stride, ranks)` is called on
+    the current stream to write the summed gradients (the HIP entry in the product; tests pass their own)."""
+
+    factors = True
+
+    def __init__(self, grad: torch.Tensor, group=None, bounds: Sequence[int] = (), force: bool = False,
+                 linear_ranges: Sequence[Tuple[int, int]] = ()):
+        super().__init__(grad, group, bounds, force, payload="fp32", algorithm="all_reduce")
+        head_end = self.buckets[1][1] if len(self.buckets) > 1 else grad.numel()
+        self.head_end = head_end
+        self.linear_ranges = sorted((int(a), int(b)) for a, b in linear_ranges)
+        self.small_ranges = _complement(self.linear_ranges, 0, head_end)
+        self._recv: Optional[torch.Tensor] = None
+        self._pack_floats = 0
+
+    def start(self, k: Optional[int] = None) -> None:
+        """Buckets 0 and 1 (the head) are exchanged by start_factors(); later buckets as in the parent."""
+        if not self.active:
+            return
+        for i in (range(len(self.buckets)) if k is None else [k]):
+            if i >= 2:
+                super().start(i)
+
+    def start_factors(self, pack: torch.Tensor, form) -> None:
+        if not self.active:
+            raise RuntimeError("FactorExchange.start_factors without an active exchange (world 1 and not forced): run the plain backward")
+        n = pack.numel()
+        if self._recv is None or self._recv.numel() != n * self.world or self._recv.device != pack.device:
+            self._recv = torch.empty(n * self.world, dtype=pack.dtype, device=pack.device)
+        self._pack_floats = n
+        recv, world = self._recv, self.world
+        for lo, hi in self.small_ranges:
+            w = self.comm.all_reduce_async(self.grad[lo:hi])
+            if w is not None:
+                self._pending.append(w)
+        w = self.comm.all_gather_into_async(recv, pack)
+        self._pending.append(_Joined([w], after=lambda: form(recv, n, world)))
+
+    def wire_bytes(self) -> int:
+        """Bytes one rank contributes per step: its factor pack, the small all-reduced ranges and the later buckets."""
+        small = sum(hi - lo for lo, hi in self.small_ranges)
+        later = sum(hi - lo for lo, hi in self.buckets[2:])
+        return 4 * (self._pack_floats + small + later)
 
 
 def shard_indices(n: int, world: int, rank: int, perm: Optional[torch.Tensor] = None, pad: bool = True) -> torch.Tensor:

@@ -126,11 +126,13 @@ class HeadStep:
             L.check(lib.ufnd_softmax_ce(b["logits"].data_ptr(), b["label"].data_ptr(), B, None,
                                         b["dlogits"].data_ptr() if with_loss_grad else None, st, s), "ufnd_softmax_ce")
 
-    def enqueue_backward(self, b: dict, B: int, part: int = 0) -> None:
+    def enqueue_backward(self, b: dict, B: int, part: int = 0, linear_grads: bool = True) -> None:
         """part 0: the whole backward; 1: classifier backward + the fuse_mlp phase of the fusion backward (bucket 0 of
-        the gradient exchange is complete afterwards); 2: the rest of the fusion backward."""
+        the gradient exchange is complete afterwards); 2: the rest of the fusion backward.  linear_grads=False leaves the
+        Linear layers' dW / db products out (factor exchange: linear_grads_from_factors forms them over all ranks' rows)."""
         lib, s, st = L.lib(), L.stream_ptr(self.device), self.optim.state.ptr
         d = b["dims"]
+        skip = 0 if linear_grads else L.BWD_NO_LINEAR_GRADS
         # Eager launches: dW / parameter-gradient kernels run beside the dX chain on a second stream (joined
         # at the end).  Inside a captured hipGraph the fork/join costs more than it hides (ROCm 7 replays
         # multi-branch graphs almost serially -- measured), so the graph keeps one stream.
@@ -140,14 +142,57 @@ class HeadStep:
                 self._dw_stream = torch.cuda.Stream(device=self.device)
             side = self._dw_stream.cuda_stream
         if part != 2:
-            L.check(lib.ufnd_classifier_backward(C.byref(d), C.byref(self.clf.param_table()), C.byref(self.clf.grad_table()), B, 1,
-                                                 b["cws"].data_ptr(), b["dlogits"].data_ptr(), b["dfused"].data_ptr(),
-                                                 self.fusion.hidden, st, s, side, 0), "ufnd_classifier_backward")
+            L.check(lib.ufnd_classifier_backward_ex(C.byref(d), C.byref(self.clf.param_table()), C.byref(self.clf.grad_table()), B, 1,
+                                                    b["cws"].data_ptr(), b["dlogits"].data_ptr(), b["dfused"].data_ptr(),
+                                                    self.fusion.hidden, st, s, side, 0, skip), "ufnd_classifier_backward")
         L.check(lib.ufnd_fusion_backward_phase(C.byref(d), C.byref(self.fusion.param_table()), C.byref(self.fusion.grad_table()),
                                                b["text"].data_ptr(), b["audio"].data_ptr(), b["visual"].data_ptr(),
                                                b["temporal"].data_ptr(), b["gnn"].data_ptr(), B, 1, b["fws"].data_ptr(),
                                                b["dfused"].data_ptr(), self.fusion.hidden, None, st, s, side, 1,
-                                               (L.BWD_ALL, L.BWD_FUSE_MLP, L.BWD_REST)[part]), "ufnd_fusion_backward_phase")
+                                               (L.BWD_ALL, L.BWD_FUSE_MLP, L.BWD_REST)[part] | skip), "ufnd_fusion_backward_phase")
+
+    # ------------------------------------------------------------------ factor form of the gradient exchange (dp.FactorExchange)
+    def factor_pack(self, b: dict, B: int) -> torch.Tensor:
+        """The rank's factor panels of this step's backward (run with linear_grads=False) in one contiguous buffer: ONE launch."""
+        if "pack" not in b:
+            b["pack"] = torch.empty(L.lib().ufnd_head_factor_floats(C.byref(b["dims"]), B), dtype=torch.float32, device=self.device)
+        L.check(L.lib().ufnd_head_pack_factors(C.byref(b["dims"]), b["text"].data_ptr(), b["audio"].data_ptr(), b["visual"].data_ptr(),
+                                               b["temporal"].data_ptr(), b["gnn"].data_ptr(), B, b["fws"].data_ptr(), b["cws"].data_ptr(),
+                                               b["pack"].data_ptr(), L.stream_ptr(self.device)), "ufnd_head_pack_factors")
+        return b["pack"]
+
+    def linear_grads_from_factors(self, b: dict, B: int, packs: torch.Tensor, stride: int, ranks: int) -> None:
+        """The summed dW / db of the head's 13 Linear layers over ranks x B rows, from the gathered packs: ONE grouped launch."""
+        if packs.device != self.device or packs.dtype != torch.float32 or packs.numel() < stride * ranks:
+            raise RuntimeError(f"gathered factor packs: {packs.numel()} {packs.dtype} values on {packs.device} for {ranks} ranks of {stride}")
+        L.check(L.lib().ufnd_head_linear_grads_from_factors(C.byref(b["dims"]), C.byref(self.fusion.grad_table()), C.byref(self.clf.grad_table()),
+                                                            packs.data_ptr(), stride, ranks, B, L.stream_ptr(self.device)),
+                "ufnd_head_linear_grads_from_factors")
+
+    def _fwd_bwd_factors(self, b: dict, B: int, post: Callable[[], None], tail: Callable[[], None]) -> None:
+        """fwd_bwd with the factor exchange: the backward leaves the Linear products out and packs its factor panels; the packs are
+        all-gathered while `tail()` runs; reducer.finish() forms the summed Linear gradients (one launch over world x B rows)."""
+        def body():
+            self.enqueue_forward(b, B, True, True)
+            self.enqueue_backward(b, B, 0, linear_grads=False)
+            self.factor_pack(b, B)
+        if not self.head_graph:
+            body()
+        else:
+            if b.get("graph_factors") is None:
+                side = torch.cuda.Stream(device=self.device)
+                side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(side):          # warm-up outside capture (lazy module loads etc.)
+                    body()
+                torch.cuda.current_stream(self.device).wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    body()
+                b["graph_factors"] = g
+            b["graph_factors"].replay()
+        post()                          # (the integrated variant's GNN backward: its gradients are in the all-reduced ranges)
+        self.reducer.start_factors(b["pack"], lambda packs, stride, ranks: self.linear_grads_from_factors(b, B, packs, stride, ranks))
+        tail()
 
     def feature_grads(self, b: dict, B: int, d_text: Optional[torch.Tensor], d_visual: Optional[torch.Tensor]) -> None:
         """d loss / d text_features, d loss / d visual_features out of the workspace the fusion backward has filled (where the
@@ -165,6 +210,8 @@ class HeadStep:
         dp = self.reducer.active
         post = post or (lambda: None)
         tail = tail or (lambda: None)
+        if dp and getattr(self.reducer, "factors", False):
+            return self._fwd_bwd_factors(b, B, post, tail)
 
         def first():
             self.enqueue_forward(b, B, True, True)

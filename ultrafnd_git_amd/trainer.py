@@ -39,7 +39,7 @@ from . import _lib as L
 from .arena import rehome
 from .classifier import DeepTruthClassifier
 from .data import CachedTensorDataset, DeviceBatchLoader, IndexedBatch, _batch_size, synthetic_cache  # noqa: F401  (re-exported)
-from .dp import GradReducer, as_comm, broadcast_from_rank0, gather_epoch_outputs, save_checkpoint
+from .dp import FactorExchange, GradReducer, as_comm, broadcast_from_rank0, gather_epoch_outputs, save_checkpoint
 from .fusion import CrossModalTransformer
 from .head_step import HeadStep
 from .metrics import aggregate_epoch_metrics, pretty_print
@@ -87,7 +87,8 @@ class TrainConfig:
     # the loader rotates a small fixed set of device input buffers (bench.py: four): encoder graphs read them in place, one graph
     # per buffer set (pipeline.py).  False: every batch that is not one of the trainer's own group buffers is staged.
     persistent_inputs: bool = False
-    # gradient exchange variants (dp.py): payload "fp32" | "bf16", algorithm "all_reduce" | "rs_ag"
+    # gradient exchange variants (dp.py): payload "fp32" | "bf16", algorithm "all_reduce" | "rs_ag" | "factors" (the head's Linear
+    # gradients formed from all-gathered factor panels instead of being reduced: 20 x fewer bytes per rank; fp32 payload only)
     grad_payload: str = "fp32"
     grad_exchange: str = "all_reduce"
     # fine-tune the encoders with the head (encoder_train.py: forward with saved activations + hand-written backward; needs
@@ -183,8 +184,14 @@ class ForensicTrainer:
             self.vis_bp.bind(self.arena, "vis.")
             bounds += [self.arena.offsets[extra[0][0][0]][0], self.arena.offsets["vis." + self.vis_bp.groups()[0][0][0]][0]]
             self._enc_dirty = False
-        self.reducer = GradReducer(self.arena.ensure_grad(), group=self.comm, bounds=bounds,
-                                   force=force_exchange, payload=cfg.grad_payload, algorithm=cfg.grad_exchange)
+        if cfg.grad_exchange == "factors":
+            if cfg.grad_payload != "fp32":
+                raise ValueError('grad_exchange="factors" moves fp32 factor panels: grad_payload must stay "fp32"')
+            self.reducer = FactorExchange(self.arena.ensure_grad(), group=self.comm, bounds=bounds, force=force_exchange,
+                                          linear_ranges=self._linear_grad_ranges())
+        else:
+            self.reducer = GradReducer(self.arena.ensure_grad(), group=self.comm, bounds=bounds,
+                                       force=force_exchange, payload=cfg.grad_payload, algorithm=cfg.grad_exchange)
         if self.text_bp is not None and self.world > 1:
             # the encoders are built by the caller, before this constructor seeds anything: replicas may start from different RNG
             # states.  They only ever exchange gradients, so unequal masters would silently stay unequal.
@@ -215,6 +222,31 @@ class ForensicTrainer:
         self.best_val_auc = -1.0
         self.no_improve = 0
         self.ckpt_path = os.path.join(cfg.out_dir, "best.pt")
+
+    def _linear_grad_ranges(self):
+        """[begin, end) float ranges of the gradient arena written by the head's Linear dW / db products (what the factor exchange
+        forms instead of reducing); a range runs to the next tensor's offset, i.e. over the alignment gap behind it."""
+        linear = {"clf.pre.0.weight", "clf.pre.0.bias", "clf.pre.3.weight", "clf.pre.3.bias",
+                  "fusion.fuse_mlp.0.weight", "fusion.fuse_mlp.0.bias", "fusion.fuse_mlp.3.weight", "fusion.fuse_mlp.3.bias"}
+        for k in self.arena.grad_keys:
+            if k.startswith("fusion.") and (k.endswith("_proj.weight") or k.endswith("_proj.bias")) and "evidence" not in k and "semantic" not in k:
+                linear.add(k)
+            if k.startswith("fusion.attn_") and k.rsplit(".", 2)[-2] in ("q", "k", "v"):
+                linear.add(k)
+        order = sorted(self.arena.grad_keys, key=lambda k: self.arena.offsets[k][0])
+        out = []
+        for i, k in enumerate(order):
+            if k in linear:
+                lo = self.arena.offsets[k][0]
+                hi = self.arena.offsets[order[i + 1]][0] if i + 1 < len(order) else self.arena.n_grad
+                if out and out[-1][1] == lo:
+                    out[-1] = (out[-1][0], hi)
+                else:
+                    out.append((lo, hi))
+        n_lin = 2 + 2 + 9 + (5 if self.fusion.use_gnn else 4)          # pre.0/.3, fuse_mlp.0/.3, nine q/k/v, the input projections
+        if len(linear) != 2 * n_lin:
+            raise RuntimeError(f"factor exchange: expected {2 * n_lin} Linear weight / bias tensors in the head, found {len(linear)}")
+        return out
 
     # ------------------------------------------------------------------ data
     def _build_dataloaders(self):
