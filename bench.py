@@ -164,12 +164,21 @@ def exchange_probe(tr, dev, n: int = 20):
     g.zero_()
     was = tr.reducer.force
     tr.reducer.force = True                    # (world 1 under torchrun: run the collectives anyway)
+    factors = getattr(tr.reducer, "factors", False)
+    if factors:                                # the factor form: all-gather of one pack + the small all-reduces + the grouped dW launch over all ranks' rows
+        B = tr.cfg.batch_size
+        hb = tr.head.bufs(B, True, 0)
+        hb["fws"].zero_(); hb["cws"].zero_()
+        pack = tr.head.factor_pack(hb, B)
+        form = lambda p, s_, r: tr.head.linear_grads_from_factors(hb, B, p, s_, r)
     times = []
     for _ in range(n + 3):
         torch.cuda.synchronize(dev)
         dist.barrier()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+        if factors:
+            tr.reducer.start_factors(pack, form)
         tr.reducer.start()
         tr.reducer.finish()
         e1.record()
@@ -178,9 +187,12 @@ def exchange_probe(tr, dev, n: int = 20):
     tr.reducer.force = was
     t = torch.tensor([statistics.median(times[3:])], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return {"ranks_seen": dist.get_world_size(), "allreduce_ms": round(float(t.item()), 4), "bytes": int(g.numel()) * 4,
-            "buckets": len(tr.reducer.buckets), "backend": dist.get_backend(),
-            "what": f"median of {n} two-bucket sum-all-reduces of the fp32 gradient arena, alone on the GPU, max over ranks"}
+    what = (f"median of {n} factor exchanges (all-gather of the rank's {tr.reducer.wire_bytes()} B of factor panels and small gradient ranges, then the "
+            "summed Linear gradients formed over all ranks' rows in one launch), alone on the GPU, max over ranks" if factors else
+            f"median of {n} {len(tr.reducer.buckets)}-bucket sum-all-reduces of the fp32 gradient arena, alone on the GPU, max over ranks")
+    return {"ranks_seen": dist.get_world_size(), "allreduce_ms": round(float(t.item()), 4), "bytes": int(tr.reducer.wire_bytes()),
+            "buckets": len(tr.reducer.buckets), "backend": dist.get_backend(), "algorithm": "factors" if factors else tr.reducer.algorithm,
+            "what": what}
 
 
 def bench_train_encoders(args, dev, world, rank):
@@ -318,6 +330,9 @@ def main():
                     help="secondary measurement: the reference's actual training mode (cached features, no encoders in the step)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="under torchrun at world 1: run the bucketed gradient exchange anyway (the RCCL path's fixed cost on one GPU)")
+    ap.add_argument("--grad-exchange", choices=("all_reduce", "rs_ag", "factors"), default="all_reduce",
+                    help="data-parallel exchange of the head's gradients (dp.py): bucketed all-reduce (default), reduce-scatter + all-gather, or "
+                         "all-gathered factor panels with the Linear gradients formed locally over all ranks' rows")
     ap.add_argument("--train-encoders", action="store_true",
                     help="secondary measurement: fine-tune both encoders with the head (forward with saved activations + hand-written "
                          "backward; the reference keeps its encoders frozen)")
@@ -358,7 +373,7 @@ def main():
     torch.manual_seed(42)
     if args.head_only:
         cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir="/tmp/ufnd_bench", batch_size=B, device=str(dev),
-                          use_graph=not args.no_graph, seed=42)
+                          use_graph=not args.no_graph, seed=42, grad_exchange=args.grad_exchange)
         tr = ForensicTrainer(cfg, cache=synthetic_cache(max(64, 8 * B), seed=1), force_exchange=args.force_exchange)
         tr.fusion.train(); tr.clf.train()
         from ultrafnd_git_amd.trainer import IndexedBatch
@@ -388,7 +403,9 @@ def main():
                               "value": round(world * B * args.steps / dt, 1), "unit": "samples/s", "ms_per_step": round(dt / args.steps * 1e3, 4),
                               "per_gpu_batch": B, "n_gpus": world, "ranks_seen": xch["ranks_seen"], "exchange": xch,
                               "steps": args.steps, "warmup": args.warmup,
-                              "gradient_exchange": "bucketed all-reduce overlapped with backward" if tr.reducer.active else "none (one rank)",
+                              "gradient_exchange": ("none (one rank)" if not tr.reducer.active else
+                                                    "factor panels all-gathered, Linear gradients formed locally" if args.grad_exchange == "factors" else
+                                                    "bucketed all-reduce overlapped with backward"),
                               "timing": {"what": f"median of {len(blocks)} blocks of {args.steps} steps",
                                          "ms_per_step_blocks": [round(x / args.steps * 1e3, 4) for x in blocks]},
                               "roofline": {"bound": "hbm", "kernel": "whole head step (26 launches; AdamW + grad-norm + the three fuse_mlp.0 GEMMs move 90 % of the bytes)",
@@ -407,7 +424,7 @@ def main():
     if args.cu_split and args.cu_split != "0":
         split = tuple(int(x) for x in args.cu_split.split(","))
     cfg = TrainConfig(data_root="", ocr_phrase_pkl=None, out_dir="/tmp/ufnd_bench", batch_size=B, device=str(dev),
-                      use_graph=not args.no_graph, encode_inline=True, seed=42, cu_split=split,
+                      use_graph=not args.no_graph, encode_inline=True, seed=42, cu_split=split, grad_exchange=args.grad_exchange,
                       persistent_inputs=True)       # (the four input buffer sets below are rotated, never reallocated)
     tenc.fuse_qkv_attention = not args.no_fuse_attn
     for enc, spec in ((tenc, args.text_tiles), (venc, args.vis_tiles)):
