@@ -197,7 +197,7 @@ int ufnd_classifier_backward_ex(const ufnd_dims* d, const ufnd_clf_params* p, co
  *      contiguous pack of ufnd_head_factor_floats(d, B) floats (one launch; 2.5 MB at B = 32, hidden 512);
  *   3. all-gather the packs (rank r's pack at packs + r * rank_stride);
  *   4. ufnd_head_linear_grads_from_factors: the SUMMED dW / db of every Linear over ranks * B rows, written into the
- *      gradient tables in one grouped launch (fp32 MFMA; rows in rank order, so every rank computes the same bits).
+ *      gradient tables in one grouped launch, two when (hidden + aux_dim) % 4 != 0 (fp32 MFMA; rows in rank order, so every rank computes the same bits).
  * The remaining gradients (gates, thresholds, leaves, bypass, evidence_proj: 21 k floats) are summed by an ordinary
  * all-reduce.  ranks == 1 reproduces the plain backward's dW / db bit for bit.
  * ---------------------------------------------------------------------------------- */
@@ -589,6 +589,38 @@ size_t ufnd_gemm_bf16_wgrad_workspace_floats(int n_out, int k_in, int tokens);
 int ufnd_gemm_bf16_wgrad(const void* dYt, const void* Xt, float* dW, int n_out, int k_in, int tokens, int lda, int ldb, int ldw,
                          float* workspace, int accumulate, void* stream);
 
+/* A LayerNorm's deferred parameter-gradient finish (ufnd_layernorm_bwd with accumulate = UFND_PARTIALS_DEFER leaves the block
+ * partials part[blk][2][H] in its workspace): out0 (H) = dgamma, out1 (H) = dbeta, the nblk blocks added in ascending order. */
+typedef struct ufnd_partials_job {
+  const float* part;
+  int nblk, H;
+  float *out0, *out1;
+} ufnd_partials_job;
+#define UFND_PARTIALS_DEFER 2
+
+/* One Linear's weight and bias gradient from the row-major activations, in THREE launches (round 4; the five-launch sequence
+ * ufnd_transpose_bf16 x 2 + column-sum finish + ufnd_gemm_bf16_wgrad + slab reduce stays available):
+ *   dW (N, K) fp32 = dY (M, N)^T x X (M, K), db (N) = column sums of dY (NULL: skipped); both OVERWRITTEN.
+ *   1. both operand transposes (dYt (N, ldt), Xt (K, ldt), ldt >= M rounded up to 64; zero-padded) + dY's column-sum partials;
+ *   2. the NT kernel over the token dimension in slices (slab_workspace: ufnd_gemm_bf16_wgrad_workspace_floats(N, K, Mpad));
+ *   3. ONE finish launch: slab reduce of dW, column-sum finish of db (colsum_workspace: ufnd_transpose_colsum_workspace_floats)
+ *      and, if `extra` != NULL, a deferred LayerNorm dgamma / dbeta finish.
+ * Same arithmetic in the same order as the five-launch sequence: bit-identical gradients. */
+int ufnd_linear_wgrad(const void* dY, int lddy, const void* X, int ldx, int M, int N, int K, float* dW, float* db, void* dYt, void* Xt, int ldt,
+                      float* slab_workspace, float* colsum_workspace, const ufnd_partials_job* extra, void* stream);
+
+/* bf16 W (rows, ld_w) and W^T (cols, ld_wt) of MANY Linears from their fp32 masters (rows, ld_master) in ONE launch (after an
+ * optimizer step).  rows and cols multiples of 64, every pointer 16-B aligned, ld_master % 4 == 0, ld_w % 8 == 0, ld_wt % 8 == 0;
+ * tile0 = the item's first 64 x 64 tile in the launch (items sorted by it: tile0 of item i + (rows/64)(cols/64) = tile0 of item i+1);
+ * `items_device` is a DEVICE-resident table (it is read by the kernel), total_tiles the sum over the items. */
+typedef struct ufnd_refresh_item {
+  const void* master;
+  void* w;
+  void* wt;
+  int rows, cols, ld_master, ld_w, ld_wt, tile0;
+} ufnd_refresh_item;
+int ufnd_refresh_operands(const ufnd_refresh_item* items_device, int n_items, int total_tiles, void* stream);
+
 /* dst (cols, ldd) bf16 = src (rows, lds)^T, columns rows..rows_pad-1 zero; src bf16, or fp32 (src_is_f32: cast on the way --
  * weight masters to transposed operand copies).  colsum != NULL (bf16 sources): colsum (cols) [+]= the column sums of src
  * (bias gradients: db = sum over tokens of dy), two-stage through colsum_ws (ufnd_transpose_colsum_workspace_floats). */
@@ -607,8 +639,12 @@ int ufnd_attention_bf16_bwd(const void* qkv, const void* ctx, const void* dctx, 
 
 /* LayerNorm backward: dx = rstd (g - mean(g) - xh mean(g xh)) [+ add], g = dy gamma, xh = (x - mean) rstd, from the LayerNorm's
  * INPUT x (M rows of stride ldx); dx as fp32 and / or bf16 (stride lddx).  dgamma / dbeta (H) [+]= their row sums (two-stage,
- * through `workspace`: ufnd_layernorm_bwd_workspace_floats); both may be NULL (then workspace may be too). */
+ * through `workspace`: ufnd_layernorm_bwd_workspace_floats); both may be NULL (then workspace may be too).
+ * accumulate = UFND_PARTIALS_DEFER: only the block partials are written (ufnd_layernorm_bwd_blocks(M) blocks); the caller hands
+ * them to ufnd_linear_wgrad (`extra`) or ufnd_row_partials_finish before the workspace is reused -- dgamma / dbeta are not touched. */
 size_t ufnd_layernorm_bwd_workspace_floats(int M, int H);
+int ufnd_layernorm_bwd_blocks(int M);
+int ufnd_row_partials_finish(const ufnd_partials_job* job, int accumulate, void* stream);
 int ufnd_layernorm_bwd(const float* x, int ldx, const float* gamma, const float* dy, int lddy, const float* add, int ldadd, float* dx_f32,
                        void* dx_bf16, int lddx, float* dgamma, float* dbeta, float* workspace, int accumulate, int M, int H, float eps,
                        void* stream);

@@ -63,6 +63,20 @@ class TcnLayer(C.Structure):
     _fields_ = [(n, _FP) for n in ("w", "b", "gamma", "beta", "running_mean", "running_var")]
 
 
+class PartialsJob(C.Structure):
+    """ufnd_partials_job: a LayerNorm's deferred dgamma / dbeta finish."""
+    _fields_ = [("part", C.c_void_p), ("nblk", C.c_int), ("H", C.c_int), ("out0", C.c_void_p), ("out1", C.c_void_p)]
+
+
+class RefreshItem(C.Structure):
+    """ufnd_refresh_item: one Linear of a grouped bf16 operand refresh."""
+    _fields_ = [("master", C.c_void_p), ("w", C.c_void_p), ("wt", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("ld_master", C.c_int),
+                ("ld_w", C.c_int), ("ld_wt", C.c_int), ("tile0", C.c_int)]
+
+
+PARTIALS_DEFER = 2
+
+
 class GemmLn(C.Structure):
     """ufnd_gemm_ln: the LayerNorm extras of ufnd_gemm_bf16_ln."""
     _fields_ = [("a_stats", _FP), ("colsum", _FP), ("r_stats", _FP), ("r_gamma", _FP), ("r_beta", _FP), ("out_stats", _FP),
@@ -160,6 +174,10 @@ def _declare_encoders(lib: C.CDLL) -> None:
         "ufnd_gemm_bf16_dgrad": [P] * 6 + [I] * 10 + [P],
         "ufnd_gemm_bf16_wgrad": [P, P, P, I, I, I, I, I, I, P, I, P],
         "ufnd_transpose_bf16": [P, I, I, I, I, P, I, I, P, P, I, P],
+        "ufnd_linear_wgrad": [P, I, P, I, I, I, I, P, P, P, P, I, P, P, C.POINTER(PartialsJob), P],
+        "ufnd_refresh_operands": [P, I, I, P],
+        "ufnd_layernorm_bwd_blocks": [I],
+        "ufnd_row_partials_finish": [C.POINTER(PartialsJob), I, P],
         "ufnd_attention_bf16_lse": [P, P, P, P, I, I, I, P],
         "ufnd_attention_bf16_bwd": [P, P, P, P, P, P, P, I, I, I, P],
         "ufnd_layernorm_bwd": [P, I, P, P, I, P, I, P, P, I, P, P, P, I, I, I, F, P],

@@ -119,50 +119,69 @@ __global__ __launch_bounds__(256) void row_partials_finish_kernel(const float* _
   }
 }
 
-// masked mean-pool + L2 backward (text_blocks.py:82-86,100): one block per sample.
+// masked mean-pool + L2 backward (text_blocks.py:82-86,100).
 //   rep = sum_t m_t h_t / max(count, 1e-6);  f = rep / (|rep| + 1e-9)
 //   drep = df / (n + e) - rep (rep . df) / (n (n + e)^2);  dh_t = m_t / max(count, 1e-6) drep
-__global__ __launch_bounds__(256) void meanpool_l2_bwd_kernel(const float* __restrict__ hidden, const int32_t* __restrict__ mask,
-                                                              const float* __restrict__ dfeat, float* __restrict__ dhidden, int L, int H) {
-  __shared__ float sh[2][4];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  float rep[4] = {0.f, 0.f, 0.f, 0.f};
+// grid (B, MP_SPLIT): every block of a sample rebuilds rep (its 4 row groups take tokens l = g, g + 4, ... with 16-B loads, eight
+// in flight; the groups meet in LDS and are added in group order) and writes the gradient rows of its quarter of the tokens.  (One
+// block of 256 threads per sample walking the tokens one 4-B load at a time took 189 us at 32 x 128 tokens: the 32 blocks'
+// dependent loads, not bytes.)
+constexpr int MP_SPLIT = 4, MP_GROUPS = 4;
+__global__ __launch_bounds__(1024) void meanpool_l2_bwd_kernel(const float* __restrict__ hidden, const int32_t* __restrict__ mask,
+                                                               const float* __restrict__ dfeat, float* __restrict__ dhidden, int L, int H) {
+  __shared__ f32x4 acc[MP_GROUPS][256];
+  __shared__ float red[2][16];
+  __shared__ float cnt_sh[MP_GROUPS];
+  const int b = blockIdx.x, tid = threadIdx.x, g = tid >> 8, c4 = tid & 255;      // 256 threads x 4 columns cover H <= 1024
+  const bool live_col = 4 * c4 < H;
+  f32x4 rep = {0.f, 0.f, 0.f, 0.f};
   float cnt = 0.0f;
-  for (int l = 0; l < L; ++l) {
-    if (mask[(size_t)b * L + l] != 0) {
-      cnt += 1.0f;
-      int n = 0;
-      for (int c = tid; c < H; c += 256, ++n) rep[n] += hidden[((size_t)b * L + l) * H + c];
+  const int32_t* mrow = mask + (size_t)b * L;
+  const float* hb = hidden + (size_t)b * L * H + 4 * c4;
+  for (int l0 = g; l0 < L; l0 += MP_GROUPS * 8) {
+    f32x4 v[8];
+    bool on[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int l = l0 + MP_GROUPS * u;
+      on[u] = l < L && mrow[l] != 0;
+      v[u] = (on[u] && live_col) ? ld4(hb + (size_t)l * H) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (on[u]) { rep += v[u]; cnt += 1.0f; }
   }
+  acc[g][c4] = rep;
+  if (c4 == 0) cnt_sh[g] = cnt;
+  __syncthreads();
+  rep = ((acc[0][c4] + acc[1][c4]) + acc[2][c4]) + acc[3][c4];
+  cnt = ((cnt_sh[0] + cnt_sh[1]) + cnt_sh[2]) + cnt_sh[3];
   const float denom = fmaxf(cnt, 1e-6f);
+  const f32x4 df = live_col ? ld4(dfeat + (size_t)b * H + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
   float sq = 0.0f, dot = 0.0f;
-  {
-    int n = 0;
-    for (int c = tid; c < H; c += 256, ++n) {
-      rep[n] /= denom;
-      sq += rep[n] * rep[n];
-      dot += rep[n] * dfeat[(size_t)b * H + c];
-    }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    rep[k] /= denom;
+    sq += rep[k] * rep[k];
+    dot += rep[k] * df[k];
   }
+  if (g != 0) { sq = 0.0f; dot = 0.0f; }      // (every group holds the same rep: group 0's lanes carry the sums)
   sq = wave_sum(sq);
   dot = wave_sum(dot);
-  if ((tid & 63) == 0) { sh[0][tid >> 6] = sq; sh[1][tid >> 6] = dot; }
+  if ((tid & 63) == 0) { red[0][tid >> 6] = sq; red[1][tid >> 6] = dot; }
   __syncthreads();
-  const float nrm = sqrtf((sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]));
-  const float dt = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+  const float nrm = sqrtf((red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+  const float dt = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
   const float ne = nrm + 1e-9f;
   const float k1 = 1.0f / ne, k2 = nrm > 0.0f ? dt / (nrm * ne * ne) : 0.0f;
-  float drep[4];
-  {
-    int n = 0;
-    for (int c = tid; c < H; c += 256, ++n) drep[n] = (dfeat[(size_t)b * H + c] * k1 - rep[n] * k2) / denom;
-  }
-  for (int l = 0; l < L; ++l) {
-    const bool live = mask[(size_t)b * L + l] != 0;
-    int n = 0;
-    for (int c = tid; c < H; c += 256, ++n) dhidden[((size_t)b * L + l) * H + c] = live ? drep[n] : 0.0f;
-  }
+  f32x4 drep;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) drep[k] = (df[k] * k1 - rep[k] * k2) / denom;
+  if (!live_col) return;
+  const int per = (L + MP_SPLIT - 1) / MP_SPLIT, l_lo = blockIdx.y * per, l_hi = l_lo + per < L ? l_lo + per : L;
+  float* db_ = dhidden + (size_t)b * L * H + 4 * c4;
+  for (int l = l_lo + g; l < l_hi; l += MP_GROUPS)
+    *reinterpret_cast<f32x4*>(db_ + (size_t)l * H) = mrow[l] != 0 ? drep : f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
 // frame pooling backward (l2norm_frames_kernel): u_f = e_f / (|e_f| + eps); F == 1: feat = u_0; else m = mean_f u_f, feat = m / (|m| + eps)
@@ -338,21 +357,34 @@ extern "C" int ufnd_layernorm_bwd(const float* x, int ldx, const float* gamma, c
   UFND_REQUIRE((!dgamma && !dbeta) || workspace, "layernorm_bwd: parameter gradients need the workspace (ufnd_layernorm_bwd_workspace_floats)");
   hipStream_t stream = (hipStream_t)stream_;
   const int nblk = ln_bwd_blocks(M);
-  float* part = (dgamma || dbeta) ? workspace : nullptr;
+  const bool defer = accumulate == UFND_PARTIALS_DEFER;
+  UFND_REQUIRE(!defer || workspace, "layernorm_bwd: deferred parameter gradients need the workspace");
+  float* part = (dgamma || dbeta || defer) ? workspace : nullptr;
   NI_LAUNCH(H, layernorm_bwd_kernel, dim3(nblk), stream, x, ldx, gamma, dy, lddy, add, ldadd, dx_f32, (__bf16*)dx_bf16, lddx, part, M, H, eps);
   UFND_CHECK_LAUNCH();
-  if (part) {
+  if (part && !defer) {
     hipLaunchKernelGGL(row_partials_finish_kernel, dim3(ufnd_cdiv(H, 16), 2), dim3(256), 0, stream, part, nblk, H, dgamma, dbeta, accumulate);
     UFND_CHECK_LAUNCH();
   }
   return UFND_OK;
 }
 
+extern "C" int ufnd_layernorm_bwd_blocks(int M) { return M >= 1 ? ln_bwd_blocks(M) : 0; }
+
+extern "C" int ufnd_row_partials_finish(const ufnd_partials_job* job, int accumulate, void* stream_) {
+  UFND_REQUIRE(job && job->part && job->nblk >= 1 && job->H >= 16 && (job->out0 || job->out1) && (accumulate == 0 || accumulate == 1), "row_partials_finish: null argument");
+  hipLaunchKernelGGL(row_partials_finish_kernel, dim3(ufnd_cdiv(job->H, 16), 2), dim3(256), 0, (hipStream_t)stream_, job->part, job->nblk, job->H, job->out0,
+                     job->out1, accumulate);
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}
+
 extern "C" int ufnd_masked_meanpool_l2_bwd(const float* hidden, const int32_t* mask, const float* dfeat, float* dhidden, int B, int L, int H,
                                            void* stream_) {
   UFND_REQUIRE(hidden && mask && dfeat && dhidden && B >= 1 && L >= 1, "meanpool_bwd: null argument");
-  UFND_REQUIRE(H >= 1 && H <= 1024, "meanpool_bwd: H=%d (<= 1024)", H);
-  hipLaunchKernelGGL(meanpool_l2_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream_, hidden, mask, dfeat, dhidden, L, H);
+  UFND_REQUIRE(H >= 4 && H <= 1024 && H % 4 == 0, "meanpool_bwd: H=%d (a multiple of 4, <= 1024)", H);
+  UFND_REQUIRE(ufnd_aligned(hidden, 16) && ufnd_aligned(dfeat, 16) && ufnd_aligned(dhidden, 16), "meanpool_bwd: 16-B alignment");
+  hipLaunchKernelGGL(meanpool_l2_bwd_kernel, dim3(B, MP_SPLIT), dim3(1024), 0, (hipStream_t)stream_, hidden, mask, dfeat, dhidden, L, H);
   UFND_CHECK_LAUNCH();
   return UFND_OK;
 }

@@ -19,10 +19,10 @@ namespace {
 // on the way (weight masters -> transposed operand copies).  Optional column sums of the source (bias gradients): the block of
 // row-tile rt writes its 64 partial sums to part[rt][col]; colsum_finish adds the row-tiles in ascending order.
 template <typename TIn>
-__global__ __launch_bounds__(256) void transpose_kernel(const TIn* __restrict__ src, int rows, int cols, int lds, __bf16* __restrict__ dst,
-                                                        int ldd, int rows_pad, float* __restrict__ part) {
+__device__ __forceinline__ void transpose_tile(const TIn* __restrict__ src, int rows, int cols, int lds, __bf16* __restrict__ dst,
+                                               int ldd, int rows_pad, float* __restrict__ part, int bx, int by) {
   __shared__ __bf16 tile[64][72];                    // +8 columns: the transposed reads walk rows
-  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int r0 = by * 64, c0 = bx * 64;
   const int tr = threadIdx.x >> 3, tc = (threadIdx.x & 7) * 8;     // 32 rows x 8 chunks of 8 columns per pass
   float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const TIn* __restrict__ 
       float s = 0.f;
 #pragma unroll 8
       for (int k = 0; k < 32; ++k) s += cs[k][threadIdx.x];
-      if (c0 + (int)threadIdx.x < cols) part[(size_t)blockIdx.y * cols + c0 + threadIdx.x] = s;
+      if (c0 + (int)threadIdx.x < cols) part[(size_t)by * cols + c0 + threadIdx.x] = s;
     }
   }
   // write: dst row = source column, 8 consecutive source rows per 16-B store, transposed out of the tile by the hardware
@@ -71,13 +71,29 @@ __global__ __launch_bounds__(256) void transpose_kernel(const TIn* __restrict__ 
     if (c0 + C + i < cols && r0 + R < rows_pad) *reinterpret_cast<bf16x8*>(dst + (size_t)(c0 + C + i) * ldd + r0 + R) = u.v;
   }
 }
+template <typename TIn>
+__global__ __launch_bounds__(256) void transpose_kernel(const TIn* __restrict__ src, int rows, int cols, int lds, __bf16* __restrict__ dst,
+                                                        int ldd, int rows_pad, float* __restrict__ part) {
+  transpose_tile<TIn>(src, rows, cols, lds, dst, ldd, rows_pad, part, blockIdx.x, blockIdx.y);
+}
+// Both operands of a weight gradient in ONE launch: blockIdx.z = 0: dy (M, N) -> dyT with the column-sum partials (the bias
+// gradient), z = 1: x (M, K) -> xT.  grid.x covers the wider of the two; the other's surplus blocks leave at once.
+__global__ __launch_bounds__(256) void transpose_pair_kernel(const __bf16* __restrict__ dy, int lddy, int N, const __bf16* __restrict__ x, int ldx, int K,
+                                                             int rows, __bf16* __restrict__ dyT, __bf16* __restrict__ xT, int ldt, int rows_pad,
+                                                             float* __restrict__ part) {
+  if (blockIdx.z == 0) {
+    if ((int)blockIdx.x * 64 < N) transpose_tile<__bf16>(dy, rows, N, lddy, dyT, ldt, rows_pad, part, blockIdx.x, blockIdx.y);
+  } else {
+    if ((int)blockIdx.x * 64 < K) transpose_tile<__bf16>(x, rows, K, ldx, xT, ldt, rows_pad, nullptr, blockIdx.x, blockIdx.y);
+  }
+}
 
 // out[c] (+)= sum_t part[t][c].  16 columns x 16 row-groups per block: group j adds rows j, j + 16, ... in ascending order, the
 // groups combine in a fixed tree -- enough blocks in flight for a (tiles x cols) panel of a few MB (3 blocks of 256 serial
 // adders took 12 us per call), and still one fixed order of additions.
-__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int tiles, int cols, float* __restrict__ out, int accumulate) {
+__device__ __forceinline__ void colsum_finish_block(const float* __restrict__ part, int tiles, int cols, float* __restrict__ out, int accumulate, int bx) {
   __shared__ float sh[16][17];
-  const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
+  const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4, c = bx * 16 + cl;
   float s = 0.f;
   if (c < cols)
     for (int t = grp; t < tiles; t += 16) s += part[(size_t)t * cols + c];
@@ -94,10 +110,13 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
     out[c] = accumulate ? out[c] + a[0] : a[0];
   }
 }
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int tiles, int cols, float* __restrict__ out, int accumulate) {
+  colsum_finish_block(part, tiles, cols, out, accumulate, blockIdx.x);
+}
 
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int nslab, size_t slab_stride, size_t n, float* __restrict__ out,
-                                                          int accumulate) {
-  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 256 * 4) {
+__device__ __forceinline__ void slab_reduce_block(const float* __restrict__ slabs, int nslab, size_t slab_stride, size_t n, float* __restrict__ out,
+                                                  int accumulate, int bx, int nb) {
+  for (size_t i = ((size_t)bx * 256 + threadIdx.x) * 4; i < n; i += (size_t)nb * 256 * 4) {
     f32x4 s = *reinterpret_cast<const f32x4*>(slabs + i);
     for (int k = 1; k < nslab; ++k) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(slabs + (size_t)k * slab_stride + i);
@@ -105,6 +124,92 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     }
     if (accumulate) s += *reinterpret_cast<const f32x4*>(out + i);
     *reinterpret_cast<f32x4*>(out + i) = s;
+  }
+}
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int nslab, size_t slab_stride, size_t n, float* __restrict__ out,
+                                                          int accumulate) {
+  slab_reduce_block(slabs, nslab, slab_stride, n, out, accumulate, blockIdx.x, gridDim.x);
+}
+
+// Every ordered finish pass behind one Linear's weight-gradient product in ONE launch, by block range:
+//   [0, nb)                 the slab reduce of dW (slices added in slice order)
+//   [nb, nb + cb)           the bias gradient: column-sum partials of dy added in row-tile order (colsum_finish)
+//   [nb + cb, ... + 2 jb)   optionally a LayerNorm's dgamma / dbeta: the block partials of a layernorm_bwd launch that ran earlier
+//                           (ufnd_layernorm_bwd with UFND_PARTIALS_DEFER) added in block order -- the same arithmetic as
+//                           row_partials_finish_kernel in encoders_bwd.hip
+// (three launches per Linear and one per LayerNorm were 245 launches of 4-9 us in a trainable-encoder step).
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ slabs, int nslab, size_t slab_stride, size_t n, float* __restrict__ dW,
+                                                           int accumulate, int nb, const float* __restrict__ cs_part, int cs_tiles, int cols,
+                                                           float* __restrict__ db, int cb, ufnd_partials_job job) {
+  const int b = blockIdx.x;
+  if (b < nb) {
+    slab_reduce_block(slabs, nslab, slab_stride, n, dW, accumulate, b, nb);
+  } else if (b < nb + cb) {
+    colsum_finish_block(cs_part, cs_tiles, cols, db, accumulate, b - nb);
+  } else {
+    const int jb = (job.H + 15) / 16, k = b - nb - cb, which = k / jb;
+    float* out = which ? job.out1 : job.out0;
+    if (!out) return;                     // (block-uniform)
+    // part[blk][which][H]: a (nblk x H) panel with row stride 2 H
+    __shared__ float sh[16][17];
+    const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4, c = (k - which * jb) * 16 + cl;
+    float s = 0.f;
+    if (c < job.H)
+      for (int t = grp; t < job.nblk; t += 16) s += job.part[((size_t)t * 2 + which) * job.H + c];
+    sh[grp][cl] = s;
+    __syncthreads();
+    if (grp == 0 && c < job.H) {
+      float a[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) a[q] = sh[q][cl];
+#pragma unroll
+      for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+        for (int q = 0; q < w; ++q) a[q] += a[q + w];
+      out[c] = a[0];
+    }
+  }
+}
+
+// bf16 W and W^T of MANY Linears from their fp32 masters in one launch (after an optimizer step): tile t of the launch belongs to
+// the item whose [tile0, tile0 + tiles) range holds it (binary search over the device-resident table); a tile is 64 x 64: read
+// once (fp32, 16-B loads), written twice (bf16 rows of W; bf16 rows of W^T through the LDS tile and the transposing LDS read).
+__global__ __launch_bounds__(256) void refresh_operands_kernel(const ufnd_refresh_item* __restrict__ items, int n_items) {
+  int lo = 0, hi = n_items - 1;
+  const int t = blockIdx.x;
+  while (lo < hi) {                        // last item with tile0 <= t
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].tile0 <= t) lo = mid; else hi = mid - 1;
+  }
+  const ufnd_refresh_item it = items[lo];
+  const int local = t - it.tile0, ctiles = it.cols >> 6;
+  const int by = local / ctiles, bx = local - by * ctiles;
+  __shared__ __bf16 tile[64][72];
+  const float* src = static_cast<const float*>(it.master);
+  __bf16* w = static_cast<__bf16*>(it.w);
+  __bf16* wt = static_cast<__bf16*>(it.wt);
+  const int r0 = by * 64, c0 = bx * 64;
+  const int tr = threadIdx.x >> 3, tc = (threadIdx.x & 7) * 8;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int r = r0 + tr + 32 * p, c = c0 + tc;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src + (size_t)r * it.ld_master + c), b = *reinterpret_cast<const f32x4*>(src + (size_t)r * it.ld_master + c + 4);
+    bf16x8 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { v[q] = (__bf16)a[q]; v[4 + q] = (__bf16)b[q]; }
+    *reinterpret_cast<bf16x8*>(w + (size_t)r * it.ld_w + c) = v;
+    *reinterpret_cast<bf16x8*>(&tile[tr + 32 * p][tc]) = v;
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15, q = i >> 2, pq = i & 3;
+  const int C = 16 * wave;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int R = 32 * k + 8 * g;
+    union { s16x4 s2[2]; bf16x8 v; } u;
+    u.s2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(&tile[R + q][C + 4 * pq]));
+    u.s2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(&tile[R + 4 + q][C + 4 * pq]));
+    *reinterpret_cast<bf16x8*>(wt + (size_t)(c0 + C + i) * it.ld_wt + r0 + R) = u.v;
   }
 }
 
@@ -185,6 +290,53 @@ extern "C" int ufnd_gemm_bf16_wgrad(const void* dYt, const void* Xt, float* dW, 
   size_t want = (n / 4 + 255) / 256;
   const int blocks = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, stream, workspace, S, n, n, dW, accumulate);
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}
+
+extern "C" int ufnd_linear_wgrad(const void* dY, int lddy, const void* X, int ldx, int M, int N, int K, float* dW, float* db, void* dYt, void* Xt, int ldt,
+                                 float* slab_workspace, float* colsum_workspace, const ufnd_partials_job* extra, void* stream_) {
+  UFND_REQUIRE(dY && X && dW && dYt && Xt && slab_workspace, "linear_wgrad: null operand");
+  UFND_REQUIRE(M >= 1 && N >= 8 && N % 8 == 0 && K >= 64 && K % 64 == 0, "linear_wgrad: M=%d N=%d K=%d (N %% 8 == 0, K %% 64 == 0)", M, N, K);
+  const int Mp = (M + 63) / 64 * 64;
+  UFND_REQUIRE(ldt >= Mp && ldt % 8 == 0 && lddy >= N && lddy % 8 == 0 && ldx >= K && ldx % 8 == 0, "linear_wgrad: strides (ldt >= %d)", Mp);
+  UFND_REQUIRE(ufnd_aligned(dY, 16) && ufnd_aligned(X, 16) && ufnd_aligned(dYt, 16) && ufnd_aligned(Xt, 16) && ufnd_aligned(dW, 16) && ufnd_aligned(slab_workspace, 16),
+               "linear_wgrad: 16-B alignment");
+  UFND_REQUIRE(!db || colsum_workspace, "linear_wgrad: the bias gradient needs the column-sum workspace (ufnd_transpose_colsum_workspace_floats)");
+  UFND_REQUIRE(!extra || (extra->part && extra->nblk >= 1 && extra->H >= 16 && (extra->out0 || extra->out1)), "linear_wgrad: extra finish job");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int wide = N > K ? N : K, row_tiles = Mp / 64;
+  hipLaunchKernelGGL(transpose_pair_kernel, dim3(ufnd_cdiv(wide, 64), row_tiles, 2), dim3(256), 0, stream, (const __bf16*)dY, lddy, N, (const __bf16*)X, ldx, K, M,
+                     (__bf16*)dYt, (__bf16*)Xt, ldt, Mp, db ? colsum_workspace : (float*)nullptr);
+  UFND_CHECK_LAUNCH();
+  const int cfg = wgrad_cfg(N, K, Mp);
+  UFND_REQUIRE(K % kTiles[cfg].bn == 0, "linear_wgrad: tile %d needs K %% %d == 0", cfg, kTiles[cfg].bn);
+  const int S = wgrad_slices(N, K, Mp, cfg);
+  const size_t n = (size_t)N * K;
+  GemmArgs a{(const __bf16*)dYt, (const __bf16*)Xt, nullptr, nullptr, nullptr, slab_workspace, N, K, Mp, ldt, ldt, 0, 0, K, UFND_ACT_NONE, 0, 0, nullptr};
+  a.ksplit = S;
+  a.slab_stride = n;
+  int rc = launch_cfg(cfg, 6, a, stream);
+  if (rc != UFND_OK) return rc;
+  UFND_CHECK_LAUNCH();
+  size_t want = (n / 4 + 255) / 256;
+  const int nb = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+  const int cb = db ? ufnd_cdiv(N, 16) : 0;
+  ufnd_partials_job job{nullptr, 0, 16, nullptr, nullptr};
+  int jb = 0;
+  if (extra) {
+    job = *extra;
+    jb = 2 * ufnd_cdiv(job.H, 16);
+  }
+  hipLaunchKernelGGL(wgrad_finish_kernel, dim3(nb + cb + jb), dim3(256), 0, stream, (const float*)slab_workspace, S, n, n, dW, 0, nb,
+                     (const float*)colsum_workspace, row_tiles, N, db, cb, job);
+  UFND_CHECK_LAUNCH();
+  return UFND_OK;
+}
+
+extern "C" int ufnd_refresh_operands(const ufnd_refresh_item* items_device, int n_items, int total_tiles, void* stream_) {
+  UFND_REQUIRE(items_device && n_items >= 1 && total_tiles >= 1, "refresh_operands: items=%d tiles=%d", n_items, total_tiles);
+  hipLaunchKernelGGL(refresh_operands_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream_, items_device, n_items);
   UFND_CHECK_LAUNCH();
   return UFND_OK;
 }

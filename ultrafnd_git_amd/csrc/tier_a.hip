@@ -1452,8 +1452,16 @@ extern "C" int ufnd_head_linear_grads_from_factors(const ufnd_dims* d, const ufn
   TnProb tn[UFND_GEMM_MAX_PROB];
   int n = fusion_tn_fuse(*d, f, fusion_grads, M, tn, sg);
   n += fusion_tn_rest(*d, f, fusion_grads, M, tn + n, sg);
-  n += clf_tn(*d, c, clf_grads, M, tn + n, sg);
-  return launch_tn(tn, n, (hipStream_t)stream_);
+  // (the classifier's two problems stay a launch of their own, as in the backward: pre.0 is (hidden + aux) wide, which is not a
+  //  multiple of 4, and one such problem would put the whole grouped launch on 8-byte loads and stores)
+  const bool aux_vec4 = (d->hidden + d->aux_dim) % 4 == 0;
+  if (aux_vec4) n += clf_tn(*d, c, clf_grads, M, tn + n, sg);
+  TRY(launch_tn(tn, n, (hipStream_t)stream_));
+  if (!aux_vec4) {
+    n = clf_tn(*d, c, clf_grads, M, tn, sg);
+    TRY(launch_tn(tn, n, (hipStream_t)stream_));
+  }
+  return UFND_OK;
 }
 
 extern "C" int ufnd_softmax_ce_weighted(const float* logits, const int64_t* labels, int B, float w0, float w1, float label_smoothing,

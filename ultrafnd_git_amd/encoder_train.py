@@ -46,6 +46,8 @@ class _Backprop:
         self._ops: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}      # linear name -> (W bf16 (N, K), W^T bf16 (K, N))
         self._scratch: Dict[Tuple, dict] = {}
         self.saved: Optional[dict] = None
+        self._refresh = None               # (device table, items, tiles, names left to the per-Linear path) of the grouped operand refresh
+        self._pending_ln = None            # a LayerNorm backward's deferred dgamma / dbeta finish (rides in the next Linear's finish launch)
 
     # ------------------------------------------------------------------ parameters
     def groups(self) -> List[List[Tuple[str, Tuple[int, ...]]]]:
@@ -67,6 +69,7 @@ class _Backprop:
         self.enc._packed = None
         self.enc.weights_version += 1
         self._ops.clear()
+        self._refresh = None
 
     def _stacked(self, buf: torch.Tensor, keys: List[str]) -> torch.Tensor:
         """View of adjacent arena tensors as one matrix (q/k/v -> (3H, H)) or vector."""
@@ -91,14 +94,42 @@ class _Backprop:
         return self._stacked(self.arena.ensure_grad(), keys)
 
     def refresh_operands(self) -> None:
-        """bf16 W and W^T of every Linear from the fp32 masters (after an optimizer step; captured-graph safe: fixed buffers)."""
+        """bf16 W and W^T of every Linear from the fp32 masters (after an optimizer step; captured-graph safe: fixed buffers): ONE
+        grouped launch over all Linears whose shapes are multiples of 64 (every one of BERT-base / ViT-B), the two-launch form for
+        the rest."""
         s = L.stream_ptr(self.enc.device)
-        for name, (wk, _) in self.linears().items():
-            m = self.master(wk)
+        if self._refresh is None:
+            import ctypes as C
+            items, rest, tile0 = [], [], 0
+            for name, (wk, _) in self.linears().items():
+                m = self.master(wk)
+                m2 = m.reshape(m.shape[0], -1)
+                if name not in self._ops:
+                    self._ops[name] = (torch.empty(m2.shape, dtype=torch.bfloat16, device=m.device),
+                                       torch.empty((m2.shape[1], m2.shape[0]), dtype=torch.bfloat16, device=m.device))
+                wb, wt = self._ops[name]
+                R, Cc = m2.shape
+                ok = (R % 64 == 0 and Cc % 64 == 0 and m2.stride(1) == 1 and m2.stride(0) % 4 == 0 and m2.data_ptr() % 16 == 0 and
+                      wb.data_ptr() % 16 == 0 and wt.data_ptr() % 16 == 0)
+                if not ok:
+                    rest.append(name)
+                    continue
+                it = L.RefreshItem()
+                it.master, it.w, it.wt = m2.data_ptr(), wb.data_ptr(), wt.data_ptr()
+                it.rows, it.cols, it.ld_master, it.ld_w, it.ld_wt, it.tile0 = R, Cc, m2.stride(0), wb.stride(0), wt.stride(0), tile0
+                tile0 += (R // 64) * (Cc // 64)
+                items.append(it)
+            table = None
+            if items:
+                arr = (L.RefreshItem * len(items))(*items)
+                table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.enc.device)
+            self._refresh = (table, len(items), tile0, rest)
+        table, n_items, tiles, rest = self._refresh
+        if n_items:
+            L.check(L.lib().ufnd_refresh_operands(table.data_ptr(), n_items, tiles, s), "ufnd_refresh_operands")
+        for name in rest:
+            m = self.master(self.linears()[name][0])
             m2 = m.reshape(m.shape[0], -1)
-            if name not in self._ops:
-                self._ops[name] = (torch.empty(m2.shape, dtype=torch.bfloat16, device=m.device),
-                                   torch.empty((m2.shape[1], m2.shape[0]), dtype=torch.bfloat16, device=m.device))
             wb, wt = self._ops[name]
             L.check(L.lib().ufnd_cast_bf16(m2.data_ptr(), wb.data_ptr(), m2.numel(), s), "ufnd_cast_bf16")
             L.check(L.lib().ufnd_transpose_bf16(m2.data_ptr(), 1, m2.shape[0], m2.shape[1], m2.stride(0), wt.data_ptr(), wt.stride(0), m2.shape[0],
@@ -132,24 +163,35 @@ class _Backprop:
                                              out_f32.stride(0) if out_f32 is not None else 0, act, L.stream_ptr(dy.device)), "ufnd_gemm_bf16_dgrad")
 
     def _wgrad(self, sc: dict, dy, x, dW: torch.Tensor, db: Optional[torch.Tensor]) -> None:
-        """dW (N, K) = dy (M, N)^T x (M, K); db (N) = column sums of dy.  (Overwrites: every step writes every gradient.)"""
+        """dW (N, K) = dy (M, N)^T x (M, K); db (N) = column sums of dy.  (Overwrites: every step writes every gradient.)  Three
+        launches (ufnd_linear_wgrad): both transposes, the sliced NT product, one finish pass -- which also carries a pending
+        LayerNorm's dgamma / dbeta finish."""
+        import ctypes as C
         M, N = dy.shape
         K = x.shape[1]
-        Mp = _pad64(M)
-        lib, s = L.lib(), L.stream_ptr(dy.device)
         t1, t2 = sc["t1"], sc["t2"]
-        L.check(lib.ufnd_transpose_bf16(dy.data_ptr(), 0, M, N, dy.stride(0), t1.data_ptr(), t1.stride(0), Mp, L.ptr(db),
-                                        sc["cs"].data_ptr() if db is not None else None, 0, s), "ufnd_transpose_bf16")
-        L.check(lib.ufnd_transpose_bf16(x.data_ptr(), 0, M, K, x.stride(0), t2.data_ptr(), t2.stride(0), Mp, None, None, 0, s), "ufnd_transpose_bf16")
         dW2 = dW.reshape(N, -1)
-        L.check(lib.ufnd_gemm_bf16_wgrad(t1.data_ptr(), t2.data_ptr(), dW2.data_ptr(), N, K, Mp, t1.stride(0), t2.stride(0), K, sc["wg"].data_ptr(), 0, s),
-                "ufnd_gemm_bf16_wgrad")
+        job, self._pending_ln = self._pending_ln, None
+        L.check(L.lib().ufnd_linear_wgrad(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), M, N, K, dW2.data_ptr(), L.ptr(db), t1.data_ptr(),
+                                          t2.data_ptr(), t1.stride(0), sc["wg"].data_ptr(), sc["cs"].data_ptr(), C.byref(job) if job is not None else None,
+                                          L.stream_ptr(dy.device)), "ufnd_linear_wgrad")
+
+    def _flush_ln(self) -> None:
+        """A deferred LayerNorm finish that no Linear picked up (the next kernel is another LayerNorm backward, or the backward ends)."""
+        import ctypes as C
+        if self._pending_ln is not None:
+            job, self._pending_ln = self._pending_ln, None
+            L.check(L.lib().ufnd_row_partials_finish(C.byref(job), 0, L.stream_ptr(self.enc.device)), "ufnd_row_partials_finish")
 
     def _ln_bwd(self, sc: dict, x, ldx, gamma, dy, dx_f32, dx_bf16, lddx, dgamma, dbeta, M, add=None):
         H = self.enc.hidden
+        self._flush_ln()                   # (the workspace below may be the pending job's)
         L.check(L.lib().ufnd_layernorm_bwd(x.data_ptr(), ldx, gamma.data_ptr(), dy.data_ptr(), dy.stride(0), L.ptr(add), add.stride(0) if add is not None else 0,
-                                           L.ptr(dx_f32), L.ptr(dx_bf16), lddx, L.ptr(dgamma), L.ptr(dbeta), sc["ln"].data_ptr(), 0, M, H, self.enc.eps,
-                                           L.stream_ptr(x.device)), "ufnd_layernorm_bwd")
+                                           L.ptr(dx_f32), L.ptr(dx_bf16), lddx, L.ptr(dgamma), L.ptr(dbeta), sc["ln"].data_ptr(), L.PARTIALS_DEFER, M, H,
+                                           self.enc.eps, L.stream_ptr(x.device)), "ufnd_layernorm_bwd")
+        job = L.PartialsJob()
+        job.part, job.nblk, job.H, job.out0, job.out1 = sc["ln"].data_ptr(), L.lib().ufnd_layernorm_bwd_blocks(M), H, dgamma.data_ptr(), dbeta.data_ptr()
+        self._pending_ln = job
 
     def _attn_bwd(self, qkv, ctx, dctx, lse, mask, dqkv, ws, B, Lq):
         L.check(L.lib().ufnd_attention_bf16_bwd(qkv.data_ptr(), ctx.data_ptr(), dctx.data_ptr(), lse.data_ptr(), L.ptr(mask), dqkv.data_ptr(), ws.data_ptr(),
@@ -283,6 +325,7 @@ class TextBackprop(_Backprop):
         L.check(L.lib().ufnd_bert_embed_bwd(ids.data_ptr(), sv["ds"].data_ptr(), self.grad([ek + "word_embeddings.weight"]).data_ptr(),
                                             self.grad([ek + "position_embeddings.weight"]).data_ptr(), self.grad([ek + "token_type_embeddings.weight"]).data_ptr(),
                                             B, Lq, H, e.vocab, e.max_position, self.master([ek + "token_type_embeddings.weight"]).shape[0], s), "ufnd_bert_embed_bwd")
+        self._flush_ln()                   # (the embedding LayerNorm's dgamma / dbeta: no Linear follows it)
 
 
 # =============================================================================================
@@ -428,3 +471,4 @@ class VisualBackprop(_Backprop):
                                           self.grad([V + "embeddings.position_embedding.weight"]).data_ptr(), sv["dpe"].data_ptr(), N, e.n_patches, H, s),
                 "ufnd_vit_assemble_bwd")
         self._wgrad(scp, sv["dpe"], sv["patches"], self.grad([V + "embeddings.patch_embedding.weight"]), None)
+        self._flush_ln()
