@@ -613,93 +613,6 @@ __global__ __launch_bounds__(256) void tn_kernel(const TnArgs args) {
 }
 
 
-// Small batches (M < 128: the 32-row training step): the same 32 x 128 wave tile, but accumulator v owns the 32 CONSECUTIVE
-// columns [32 v, 32 v + 32) of the strip (4-byte accesses, 128 B contiguous per half-row) instead of every fourth column, and
-// the last 32 rows of the batch are multiplied accumulator by accumulator: the stores of accumulator v leave while the
-// matrix pipe works on v + 1.  At M = 32 the whole chip runs ONE round of these waves in lockstep -- loads, then 64 MFMAs
-// (3 waves per SIMD: 6 us), then 50 MB of stores draining at HBM rate (11 us) -- so the store phase has to start before the
-// matrix phase ends (24.7 -> see profiles/r04_head_*).  The same fp32 chain per output element as tn_kernel (rows ascending):
-// bit-identical gradients.  No alignment demands beyond 4 bytes: a (hidden + aux)-wide problem does not slow its launch.
-template <int SEG>
-__global__ __launch_bounds__(256) void tn_small_kernel(const TnArgs args) {
-  constexpr int VEC = 4;
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-  const int tile = blockIdx.x * 4 + w;
-  if (tile >= args.begin[args.nprob]) return;
-  int pi = 0;
-  for (int q = 1; q < args.nprob; ++q)
-    if (tile >= args.begin[q]) pi = q;
-  const TnProb& P = args.p[pi];
-  const int local = tile - args.begin[pi];
-  const int strips = (P.K + 32 * VEC - 1) / (32 * VEC);
-  const int strip = local % strips;
-  const int n0 = (local / strips) << 5;
-  const int c0 = strip * 32 * VEC + j;
-  bool cok[VEC];
-#pragma unroll
-  for (int v = 0; v < VEC; ++v) cok[v] = c0 + 32 * v < P.K;
-
-  f32x16 acc[VEC];
-#pragma unroll
-  for (int v = 0; v < VEC; ++v) acc[v] = zero16();
-  float dbsum = 0.0f;
-  const float* dycol = P.dY + n0 + j;
-  const float* xcol = P.X + c0;
-  constexpr int U = 4;   // 32 batch rows per pass: every load of the pass is issued before its MFMAs
-  for (int mb = 0; mb < P.M; mb += 8 * U) {
-    float a[U][4];
-    float b[U][4][VEC];
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int m = mb + 8 * u + 4 * h + e;
-        const bool ok = m < P.M;
-        size_t oy = (size_t)m * P.lddy, ox = (size_t)m * P.ldx;
-        if constexpr (SEG) {
-          const int sg = m / P.seg_rows, r = m - sg * P.seg_rows;
-          oy = (size_t)sg * P.seg_dy + (size_t)r * P.lddy;
-          ox = (size_t)sg * P.seg_x + (size_t)r * P.ldx;
-        }
-        a[u][e] = ok ? dycol[oy] : 0.0f;
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) b[u][e][v] = (ok && cok[v]) ? xcol[ox + 32 * v] : 0.0f;
-      }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) dbsum += a[u][e];
-    if (mb + 8 * U < P.M) {
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) acc[v] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e], b[u][e][v], acc[v], 0, 0, 0);
-    } else {      // the last rows: accumulator by accumulator, each one stored as soon as it is complete
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[v] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e], b[u][e][v], acc[v], 0, 0, 0);
-        if (cok[v]) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            P.dW[(size_t)n * P.ldw + c0 + 32 * v] = acc[v][r];
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  }
-  if (strip == 0 && P.db) {
-    const float s = dbsum + __shfl_xor(dbsum, 32, 64);
-    if (h == 0) P.db[n0 + j] = s;
-  }
-}
-
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -851,27 +764,34 @@ int launch_tn(const TnProb* probs, int nprob, hipStream_t stream) {
     a.p[i] = p;
   }
   const bool seg = probs[0].seg_rows != 0;
-  // (32 x 64 tiles -- VEC = 2, twice the waves, half the MFMA chain each -- were measured for the 32-row grouped launch in round 4:
-  //  head-only step 0.254-0.256 -> 0.264 ms; the 32 x 128 form stays)
-  int minM = a.p[0].M;
-  for (int i = 1; i < nprob; ++i) minM = a.p[i].M < minM ? a.p[i].M : minM;
-  const bool small = minM < 128;
-  const int VEC = (vec4 || small) ? 4 : 2;      // (the small-batch kernel makes 4-byte accesses: no alignment beyond that)
+  // Measured for the 32-row grouped launch in round 4 and not kept: 32 x 64 tiles (VEC = 2, twice the waves, half the MFMA chain each):
+  // head-only step 0.254-0.256 -> 0.264 ms; a form whose accumulator v owns 32 CONSECUTIVE columns (4-byte accesses) and stores each
+  // accumulator as soon as it is complete, so that the store phase starts under the matrix phase: 182 VGPRs (two waves per SIMD instead
+  // of three), 24.7 -> 31.0 us for the launch (profiles/r04_head_tn_small.txt).  The 32 x 128 form with 16-B accesses stays.
+  const int VEC = vec4 ? 4 : 2;
   int total = 0;
   for (int i = 0; i < nprob; ++i) {
     a.begin[i] = total;
     total += (a.p[i].N / 32) * ufnd_cdiv(a.p[i].K, 32 * VEC);
   }
   a.begin[nprob] = total;
-  if (small) {            // one wave per tile, stores overlapped with the matrix work
-    if (seg) hipLaunchKernelGGL((tn_small_kernel<1>), dim3(ufnd_cdiv(total, 4)), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((tn_small_kernel<0>), dim3(ufnd_cdiv(total, 4)), dim3(256), 0, stream, a);
-  } else if (seg) {       // gathered factors: rows addressed by segment
-    if (vec4) hipLaunchKernelGGL((tn_kernel<4, 1, 1>), dim3(total), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((tn_kernel<2, 1, 1>), dim3(total), dim3(256), 0, stream, a);
-  } else {                // batch rows split over the four waves of a workgroup (one workgroup per tile)
+  int minM = a.p[0].M;
+  for (int i = 1; i < nprob; ++i) minM = a.p[i].M < minM ? a.p[i].M : minM;
+  if (seg) {              // gathered factors: the same two forms, rows addressed by segment
+    if (minM >= 128) {
+      if (vec4) hipLaunchKernelGGL((tn_kernel<4, 1, 1>), dim3(total), dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((tn_kernel<2, 1, 1>), dim3(total), dim3(256), 0, stream, a);
+    } else {
+      if (vec4) hipLaunchKernelGGL((tn_kernel<4, 0, 1>), dim3(ufnd_cdiv(total, 4)), dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((tn_kernel<2, 0, 1>), dim3(ufnd_cdiv(total, 4)), dim3(256), 0, stream, a);
+    }
+  } else if (minM >= 128) {      // batch rows split over the four waves of a workgroup (one workgroup per tile)
     if (vec4) hipLaunchKernelGGL((tn_kernel<4, 1>), dim3(total), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((tn_kernel<2, 1>), dim3(total), dim3(256), 0, stream, a);
+  } else {
+    const int blocks = ufnd_cdiv(total, 4);
+    if (vec4) hipLaunchKernelGGL((tn_kernel<4>), dim3(blocks), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((tn_kernel<2>), dim3(blocks), dim3(256), 0, stream, a);
   }
   UFND_CHECK_LAUNCH();
   return UFND_OK;
