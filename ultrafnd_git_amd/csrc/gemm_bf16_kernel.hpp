@@ -16,6 +16,15 @@
 // Grid: one block per tile, XCD-aware (bijective) remap so that the blocks sharing an A
 // row-panel land on the same XCD's L2.
 #pragma once
+// Experiment switch (python -m ultrafnd_git_amd.build --defs=UFND_GEMM_OUT_NT=1): forward bf16 outputs with the non-temporal hint, so that a
+// streaming output does not evict the operand panels an XCD's workgroups are about to re-read.  Measured in round 4 (one box, A/B/A,
+// profiles/r04_nt_stores.txt): alone, FFN1 gains 5-9 % (104.5 -> 95.0 us on 256x256 tiles, 98.1 -> 92.2 persistent); inside the encoder
+// pass nothing gains and the fused QKV + attention launch, whose input is the previous layer's nt-stored output, loses 5 us (84.8 -> 89.5):
+// step 1.3746 -> 1.387-1.402 ms.  Off.
+#ifndef UFND_GEMM_OUT_NT
+#define UFND_GEMM_OUT_NT 0
+#endif
+
 #include <type_traits>
 
 #include "common.hpp"
@@ -667,7 +676,8 @@ void gemm_bf16_kernel(const GemmArgs a) {
           bf16x8 o;
 #pragma unroll
           for (int q = 0; q < 8; ++q) o[q] = (__bf16)v[q];
-          *reinterpret_cast<bf16x8*>(a.out_bf16 + (size_t)row * a.ldo + col) = o;
+          if constexpr (UFND_GEMM_OUT_NT && !BWD) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(a.out_bf16 + (size_t)row * a.ldo + col));
+          else *reinterpret_cast<bf16x8*>(a.out_bf16 + (size_t)row * a.ldo + col) = o;
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // patch reads done before the next row-tile overwrites it

@@ -387,7 +387,7 @@ void gemm_pp_kernel(const GemmArgs a) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) o[q] = (__bf16)v8[q];
     if constexpr (DBG & (4 | 16)) asm volatile("" : : "v"(o));
-    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rsOut, vo_out, ((m0p + prow_of(P)) * a.ldo + n0p) * 2, 0);
+    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rsOut, vo_out, ((m0p + prow_of(P)) * a.ldo + n0p) * 2, UFND_GEMM_OUT_NT ? 2 : 0);      // (aux bit 1 = nt)
   };
   auto slice_rows = [&](auto P_, const f32x4& rres) { slice_rows_a(P_); slice_rows_b(P_, rres); slice_rows_c(P_); };
 
