@@ -28,7 +28,7 @@ extern "C" {
 #define UFND_ERR_INVALID 1 /* bad argument: shape, alignment, null pointer */
 #define UFND_ERR_LAUNCH 2  /* HIP launch error */
 
-#define UFND_ABI_VERSION 4
+#define UFND_ABI_VERSION 5
 
 const char* ufnd_last_error(void);
 int ufnd_abi_version(void);

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     from ultrafnd_git_amd import _lib as L
-    assert lib.ufnd_abi_version() == L.ABI_VERSION == 4
+    assert lib.ufnd_abi_version() == L.ABI_VERSION == 5
 
 
 def test_struct_mirrors_match_header_sizes():

@@ -92,7 +92,7 @@ class GemmLn(C.Structure):
 STEP_STATE_BYTES = C.sizeof(StepState)
 BWD_ALL, BWD_FUSE_MLP, BWD_REST = 0, 1, 2
 BWD_NO_LINEAR_GRADS = 16          # OR-ed into the phase / flags: the factor form of the gradient exchange (dp.FactorExchange)
-ABI_VERSION = 4
+ABI_VERSION = 5
 FOLD_GUARD_SLOTS = 1024      # UFND_FOLD_GUARD_SLOTS
 
 _lib: Optional[C.CDLL] = None
