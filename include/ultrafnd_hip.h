@@ -207,6 +207,30 @@ int ufnd_head_pack_factors(const ufnd_dims* d, const float* text, const float* a
 int ufnd_head_linear_grads_from_factors(const ufnd_dims* d, const ufnd_fusion_params* fusion_grads, const ufnd_clf_params* clf_grads,
                                         const float* packs, size_t rank_stride, int ranks, int B, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * The head's train step over BOTH modules in two calls (round 4): forensic_trainer.py:285-291's
+ *   logits, _ = model(...); loss = F.cross_entropy(logits, y); loss.backward()
+ * with the same kernels and arithmetic as ufnd_fusion_forward -> ufnd_classifier_forward -> ufnd_softmax_ce ->
+ * ufnd_classifier_backward -> ufnd_fusion_backward_phase, minus the launches that exist only because those are five calls
+ * (classifier input preparation, the CE kernel, the activation backward between the modules, one of the two parameter-gradient
+ * launches): 26 -> 22 launches per step at B = 32.  Logits, probabilities, forensic scalars, state->loss, d_logits and every
+ * gradient are bit-identical to the five-call sequence.  The fusion writes `fused` straight into the classifier's input panel;
+ * the aux head (fusion logits) is not evaluated.  Plain mean CE only (the weighted / label-smoothed criterion keeps the
+ * five-call sequence).  `phase` as in ufnd_fusion_backward_phase (UFND_BWD_FUSE_MLP includes the classifier's backward).
+ * ---------------------------------------------------------------------------------- */
+typedef struct ufnd_head_io {
+  const float *text, *audio, *visual, *temporal, *gnn, *aux;   /* the step's inputs (gnn NULL iff dims.gnn_dim == 0, aux NULL iff aux_dim == 0) */
+  const int64_t* labels;                                        /* (B) */
+  float *fusion_workspace, *clf_workspace;                      /* ufnd_fusion_workspace_floats / ufnd_clf_workspace_floats */
+  float *logits, *probs, *forensic;                             /* (B,2), (B,2), (3,B) */
+  float* d_logits;                                              /* (B,2): written by the forward, read by the backward */
+} ufnd_head_io;
+int ufnd_head_forward_loss(const ufnd_dims* d, const ufnd_fusion_params* fusion, const ufnd_clf_params* clf, const ufnd_head_io* io, int B,
+                           int train, ufnd_step_state* state, void* stream);
+int ufnd_head_backward(const ufnd_dims* d, const ufnd_fusion_params* fusion, const ufnd_fusion_params* fusion_grads, const ufnd_clf_params* clf,
+                       const ufnd_clf_params* clf_grads, const ufnd_head_io* io, int B, int train, ufnd_step_state* state, void* stream,
+                       void* side_stream, int join, int phase);
+
 /* F.cross_entropy(logits, y), mean reduction, + its gradient (forensic_trainer.py:287).
  * labels int64 (B).  loss_rows (B) or NULL; d_logits (B,2) = (softmax - onehot)/B or NULL.
  * state->loss receives the mean (summed in a fixed order: bit-reproducible). */

@@ -328,3 +328,29 @@ def test_epoch_loop_with_encoder_lookahead_equals_the_plain_epoch_loop(tmp_path)
     for (l0, m0), (l1, m1) in zip(res[0][0], res[1][0]):
         assert l0 == l1 and m0 == m1
     assert torch.equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("B", [32, 7, 130])
+def test_two_call_head_step_is_bit_identical_to_the_five_call_sequence(tmp_path, B):
+    """ufnd_head_forward_loss + ufnd_head_backward (TrainConfig.fused_head, the default: 22 launches at B = 32) against
+    ufnd_fusion_forward -> ufnd_classifier_forward -> ufnd_softmax_ce -> ufnd_classifier_backward -> ufnd_fusion_backward_phase (26): the
+    same kernels and arithmetic, so logits, probabilities, the forensic scalars, the loss, every gradient and the parameters after
+    three dropout-on steps must not differ in a bit -- eager and captured, below and above the row-sliced parameter reductions (B > 64)."""
+    res = {}
+    for fused in (True, False):
+        for graph in (False, True):
+            torch.manual_seed(5)
+            tr = _trainer(tmp_path, B, graph, n=max(64, 4 * B), fused_head=fused)
+            assert tr.head.fused_entries == fused
+            tr.fusion.train(); tr.clf.train()
+            it = iter(tr.train_loader)
+            for _ in range(3):
+                out = tr.train_step(next(it))
+            torch.cuda.synchronize()
+            st = tr.optim.state.read()
+            res[(fused, graph)] = (out["logits"].clone(), out["probs"].clone(), out["forensic"].clone(), float(st.loss), float(st.grad_norm),
+                                   tr.arena.grad.clone(), tr.arena.data.clone())
+    ref = res[(False, False)]
+    for key, got in res.items():
+        for a, b in zip(got, ref):
+            assert (torch.equal(a, b) if isinstance(a, torch.Tensor) else a == b), key

@@ -63,6 +63,12 @@ class TcnLayer(C.Structure):
     _fields_ = [(n, _FP) for n in ("w", "b", "gamma", "beta", "running_mean", "running_var")]
 
 
+class HeadIO(C.Structure):
+    """ufnd_head_io: the buffers of the fused head step (ufnd_head_forward_loss / ufnd_head_backward)."""
+    _fields_ = [(n, C.c_void_p) for n in ("text", "audio", "visual", "temporal", "gnn", "aux", "labels", "fusion_workspace", "clf_workspace",
+                                           "logits", "probs", "forensic", "d_logits")]
+
+
 class PartialsJob(C.Structure):
     """ufnd_partials_job: a LayerNorm's deferred dgamma / dbeta finish."""
     _fields_ = [("part", C.c_void_p), ("nblk", C.c_int), ("H", C.c_int), ("out0", C.c_void_p), ("out1", C.c_void_p)]
@@ -126,6 +132,11 @@ def _declare(lib: C.CDLL) -> None:
     lib.ufnd_head_pack_factors.restype = I
     lib.ufnd_head_linear_grads_from_factors.argtypes = [C.POINTER(Dims), C.POINTER(FusionParams), C.POINTER(ClfParams), P, S, I, I, P]
     lib.ufnd_head_linear_grads_from_factors.restype = I
+    lib.ufnd_head_forward_loss.argtypes = [C.POINTER(Dims), C.POINTER(FusionParams), C.POINTER(ClfParams), C.POINTER(HeadIO), I, I, P, P]
+    lib.ufnd_head_forward_loss.restype = I
+    lib.ufnd_head_backward.argtypes = [C.POINTER(Dims), C.POINTER(FusionParams), C.POINTER(FusionParams), C.POINTER(ClfParams), C.POINTER(ClfParams),
+                                       C.POINTER(HeadIO), I, I, P, P, P, I, I]
+    lib.ufnd_head_backward.restype = I
     lib.ufnd_softmax_ce.argtypes = [P, P, I, P, P, P, P]
     lib.ufnd_softmax_ce_weighted.argtypes = [P, P, I, C.c_float, C.c_float, C.c_float, P, P, P, P]
     lib.ufnd_softmax_ce_weighted.restype = I

@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void nn_kernel(const NnArgs args) {
         for (int v = 0; v < VEC; ++v) dm[v] = dropout_mul(args.st, P.drop_p, P.drop_layer, (uint32_t)(mrow * P.drop_ld + kcol + v));
       }
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) val[v] *= gelu_grad_f(z[v]) * dm[v];
+      for (int v = 0; v < VEC; ++v) val[v] = val[v] * gelu_grad_f(z[v]) * dm[v];      // (d g) m: the order of act_bwd_kernel and of autograd (the head's fused backward swaps one for the other)
     }
     if (P.add) {
       const float* ad = P.add + (size_t)mrow * P.ldadd + kcol;
@@ -458,9 +458,7 @@ __global__ __launch_bounds__(256) void nn16_kernel(const NnArgs args) {
     if (mrow >= P.M) continue;
     float val = ((red[0][r][lane] + red[1][r][lane]) + red[2][r][lane]) + red[3][r][lane];
     if (P.actZ) {
-      float gz = gelu_grad_f(P.actZ[(size_t)mrow * P.ldz + kcol]);
-      if (P.drop_p > 0.0f) gz *= dropout_mul(args.st, P.drop_p, P.drop_layer, (uint32_t)(mrow * P.drop_ld + kcol));
-      val *= gz;
+      val = val * gelu_grad_f(P.actZ[(size_t)mrow * P.ldz + kcol]) * dropout_mul(args.st, P.drop_p, P.drop_layer, (uint32_t)(mrow * P.drop_ld + kcol));
     }
     if (P.add) val += P.add[(size_t)mrow * P.ldadd + kcol];
     P.out[(size_t)mrow * P.ldo + kcol] = val;

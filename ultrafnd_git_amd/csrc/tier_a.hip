@@ -60,7 +60,7 @@ FusionWs carve_fusion(const ufnd_dims& d, int B, float* base) {
 }
 
 struct ClfWs {
-  float *xin, *z3, *h3, *z4, *hh, *alpha, *fs, *df, *dz4, *dz3, *dl, *npart;
+  float *xin, *z3, *h3, *z4, *hh, *alpha, *fs, *df, *dz4, *dz3, *dl, *lrow, *npart;
   int ldx;
   size_t total;
 };
@@ -81,6 +81,7 @@ ClfWs carve_clf(const ufnd_dims& d, int B, float* base) {
   w.dz4 = take((size_t)B * H);
   w.dz3 = take((size_t)B * H);
   w.dl = take((size_t)B * 4);
+  w.lrow = take((size_t)B);                      // CE rows of the fused head step (node_head writes them, node_bwd's block 0 averages them)
   // node_param row-slice partials: per slice [gates TK x H | thresh 64 | bypass 2 x H | bypass bias 64 | leaves trees x 2^depth x 2]
   w.npart = take(param_slices(B) > 1 ? (size_t)param_slices(B) * ((size_t)(d.trees * d.depth + 2) * H + 128 + (size_t)d.trees * (1 << d.depth) * 2) : 0);
   w.total = o;
@@ -127,6 +128,45 @@ struct EvPtrs {
 struct EvGrads {
   float *w0[3], *b0[3], *w2[3], *b2[3];
 };
+// ---------------------------------------------------------------- the classifier's input preparation
+// Blocks [0, B): the input panel [fused | aux | 0] (the fused columns are copied only when the fusion did not write them in
+// place).  Blocks [B, B + trees * depth): alpha[tk] = softmax(gates[tk]) (deep_truth_classifier.py:64).  Its own launch ahead of the
+// classifier's GEMMs (clf_prep_kernel), or -- the fused head step -- extra blocks of the co-attention row kernel: nothing here
+// depends on the fusion's outputs when the fused columns are written in place.
+struct ClfPrep {
+  const float *fused, *aux, *gates;
+  float *xin, *alpha;
+  int ldf, aux_dim, ldx, copy_fused, blocks;      // blocks = B + trees * depth (0: no such role in this launch)
+};
+__device__ __forceinline__ void clf_prep_block(const ClfPrep& a, int B, int H, int block) {
+  __shared__ float sh[4];
+  if (block < B) {
+    const int row = block;
+    if (a.copy_fused)
+      for (int c = threadIdx.x; c < H; c += blockDim.x) a.xin[(size_t)row * a.ldx + c] = a.fused[(size_t)row * a.ldf + c];
+    if (threadIdx.x < 4)
+      a.xin[(size_t)row * a.ldx + H + threadIdx.x] = (a.aux && (int)threadIdx.x < a.aux_dim) ? a.aux[row * a.aux_dim + threadIdx.x] : 0.0f;
+    return;
+  }
+  const int tk = block - B;
+  const float* gp = a.gates + (size_t)tk * H;
+  float mx = -INFINITY;
+  for (int c = threadIdx.x; c < H; c += 256) mx = fmaxf(mx, gp[c]);
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+  __syncthreads();
+  float sm = 0;
+  for (int c = threadIdx.x; c < H; c += 256) sm += __expf(gp[c] - mx);
+  sm = wave_sum(sm);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sm;
+  __syncthreads();
+  sm = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  for (int c = threadIdx.x; c < H; c += 256) a.alpha[(size_t)tk * H + c] = __expf(gp[c] - mx) / sm;
+}
+__global__ __launch_bounds__(256) void clf_prep_kernel(ClfPrep a, int B, int H) { clf_prep_block(a, B, H, blockIdx.x); }
+
 // ---------------------------------------------------------------- co-attention + pairwise -> CAT
 // cross_modal_transformer.py:153-164 (evidence scalars), :48 (evidence gates), :44-54 and :172-178 (co-attention combine, pairwise features).
 // ONE WORKGROUP per row (round 3; one wave per row before): wave 0 the evidence scalars while waves 1-3 take one co-attention score each; then
@@ -135,7 +175,11 @@ struct EvGrads {
 // every element the same expression: the same bits as the one-wave form it replaced, a third of its chain.
 template <int NI>
 __global__ __launch_bounds__(256) void coattn_pairs_wg_kernel(float* cat, const float* qkv, float* gate_io, int B, int H, float* s_out,
-                                                              EvPtrs ev, float* evid, float* forensic) {
+                                                              EvPtrs ev, float* evid, float* forensic, ClfPrep prep) {
+  if ((int)blockIdx.x >= B) {                 // (fused head step: the classifier's input preparation rides in this launch)
+    clf_prep_block(prep, B, H, blockIdx.x - B);
+    return;
+  }
   __shared__ float e_lds[4], g_lds[4], s_lds[4];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x;
@@ -376,8 +420,8 @@ __global__ void gate_param_kernel(const float* evid, const float* dout, int B, i
 // Small batches (B <= 64, the one-pass form): ONE WAVE per (co-attention block b, hidden unit jj), lane r = batch row r -- the per-row
 // erf / exp work of a unit runs side by side on the lanes and five DPP wave sums add the rows, instead of one thread per unit walking
 // the rows one after the other on three workgroups (11.9 us at B = 32).  Rows beyond B contribute exact zeros.
-__global__ __launch_bounds__(256) void gate_param_rows_kernel(const float* evid, const float* dout, int B, int H, EvPtrs p, EvGrads g) {
-  const int b = blockIdx.x, jj = blockIdx.y * 4 + (threadIdx.x >> 6), r = threadIdx.x & 63;
+__device__ __forceinline__ void gate_param_rows_block(const float* evid, const float* dout, int B, int H, const EvPtrs& p, const EvGrads& g, int b, int by) {
+  const int jj = by * 4 + (threadIdx.x >> 6), r = threadIdx.x & 63;
   if (jj >= H) return;
   const float w00 = p.w0[b][jj * 3], w01 = p.w0[b][jj * 3 + 1], w02 = p.w0[b][jj * 3 + 2], b0 = p.b0[b][jj], w2 = p.w2[b][jj];
   float dw0[3] = {0, 0, 0}, db0 = 0, dw2 = 0, db2 = 0;
@@ -404,6 +448,16 @@ __global__ __launch_bounds__(256) void gate_param_rows_kernel(const float* evid,
     if (jj == 0) g.b2[b][0] = db2;
   }
 }
+__global__ __launch_bounds__(256) void gate_param_rows_kernel(const float* evid, const float* dout, int B, int H, EvPtrs p, EvGrads g) {
+  gate_param_rows_block(evid, dout, B, H, p, g, blockIdx.x, blockIdx.y);
+}
+// (fused head step: these blocks ride behind node_param_kernel's own, block e -> (b, by) = (e % 3, e / 3))
+struct GateRows {
+  const float *evid, *dout;
+  EvPtrs p;
+  EvGrads g;
+  int first;      // the launch's first gate block; 0: no such role
+};
 // grid (3, ceil((5 H + 1) / 256)): one element per thread, its S slice loads all in flight (3 workgroups walking 5 H elements x S
 // slices one dependent load at a time took 53 us at B = 256)
 __global__ __launch_bounds__(256) void gate_param_finish_kernel(const float* part, int S, int H, EvGrads g) {
@@ -479,38 +533,6 @@ __global__ void head2_bwd_kernel(const float* dlog, const float* Z, int B, int H
 }
 
 // ---------------------------------------------------------------- classifier pieces
-// One launch ahead of the classifier's GEMMs.  Blocks [0, B): the input panel [fused | aux | 0] (the fused columns are
-// copied only when the fusion did not write them in place).  Blocks [B, B + trees * depth): alpha[tk] = softmax(gates[tk])
-// (deep_truth_classifier.py:64).
-__global__ __launch_bounds__(256) void clf_prep_kernel(const float* fused, int ldf, const float* aux, int aux_dim, float* xin, int ldx,
-                                                       int B, int H, int copy_fused, const float* gates, float* alpha) {
-  __shared__ float sh[4];
-  if ((int)blockIdx.x < B) {
-    const int row = blockIdx.x;
-    if (copy_fused)
-      for (int c = threadIdx.x; c < H; c += blockDim.x) xin[(size_t)row * ldx + c] = fused[(size_t)row * ldf + c];
-    if (threadIdx.x < 4)
-      xin[(size_t)row * ldx + H + threadIdx.x] = (aux && (int)threadIdx.x < aux_dim) ? aux[row * aux_dim + threadIdx.x] : 0.0f;
-    return;
-  }
-  const int tk = blockIdx.x - B;
-  const float* gp = gates + (size_t)tk * H;
-  float mx = -INFINITY;
-  for (int c = threadIdx.x; c < H; c += 256) mx = fmaxf(mx, gp[c]);
-  mx = wave_max(mx);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
-  __syncthreads();
-  mx = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
-  __syncthreads();
-  float s = 0;
-  for (int c = threadIdx.x; c < H; c += 256) s += __expf(gp[c] - mx);
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
-  __syncthreads();
-  s = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-  for (int c = threadIdx.x; c < H; c += 256) alpha[(size_t)tk * H + c] = __expf(gp[c] - mx) / s;
-}
-
 // NODE ensemble + bypass + temperature softmax        deep_truth_classifier.py:54-74,88-90,164-170
 // One WORKGROUP per row (round 3; one wave per row before): its four waves take a quarter of the gates each (one batch of alpha
 // rows in flight, then that wave's reductions), the bypass rows go to waves 0 and 1, the trees are dealt round-robin; the pieces
@@ -522,7 +544,7 @@ __global__ __launch_bounds__(256) void node_head_kernel(const float* hh, const f
                                                         const float* bb, const float* temperature, int B, int H,
                                                         int trees, int depth, float node_p,
                                                         const ufnd_step_state* st, float* fs, float* logits,
-                                                        float* probs) {
+                                                        float* probs, const int64_t* labels, float* loss_rows, float* dlog) {
   __shared__ float s_lds[32], byp_lds[2], lg_lds[16][2];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x;                 // (grid = B)
@@ -597,6 +619,14 @@ __global__ __launch_bounds__(256) void node_head_kernel(const float* hh, const f
     const float e0 = __expf(a0 - mx), e1 = __expf(a1 - mx);
     probs[row * 2] = e0 / (e0 + e1);
     probs[row * 2 + 1] = e1 / (e0 + e1);
+    if (labels) {      // fused head step: this row of F.cross_entropy (forensic_trainer.py:287), the expressions of softmax_ce_kernel
+      const float cm = fmaxf(l0, l1);
+      const float lse = cm + logf(__expf(l0 - cm) + __expf(l1 - cm));
+      const int y = (int)labels[row];
+      loss_rows[row] = lse - (y ? l1 : l0);
+      dlog[row * 2] = (__expf(l0 - lse) - (y == 0 ? 1.f : 0.f)) / (float)B;
+      dlog[row * 2 + 1] = (__expf(l1 - lse) - (y == 1 ? 1.f : 0.f)) / (float)B;
+    }
   }
 }
 
@@ -606,12 +636,23 @@ __global__ __launch_bounds__(256) void node_head_kernel(const float* hh, const f
 // BEFORE the barrier that publishes df, so the loads fly under wave 0's leaf loops -- then d * alpha in ascending gate order.
 // The four partial rows meet in LDS as (P0 + P1) + (P2 + P3); the GELU derivative, the dropout mask and the store follow on
 // H / 4 threads.  (A fixed order, but not the one-wave form's: gradients agree to rounding, not bit for bit.)
+// (fused head step: block 0 also writes the batch-mean loss from the CE rows node_head left -- the reduction of softmax_ce_kernel,
+//  same order, same bits)
+__device__ __forceinline__ void ce_mean_block(const float* loss_rows, int B, ufnd_step_state* st) {
+  __shared__ float ce_sh[4];
+  float part = 0;
+  for (int r = threadIdx.x; r < B; r += 256) part += loss_rows[r];
+  part = wave_sum(part);
+  if ((threadIdx.x & 63) == 0) ce_sh[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) st->loss = ((ce_sh[0] + ce_sh[1]) + (ce_sh[2] + ce_sh[3])) / (float)B;
+}
 template <int NI>
 __global__ __launch_bounds__(256) void node_bwd_kernel(const float* dlog, const float* fs, const float* alpha,
                                                        const float* leaf, const float* tau, const float* bw,
                                                        const float* z4, int B, int H, int trees, int depth,
                                                        float node_p, float clf_p, const ufnd_step_state* st,
-                                                       float* df, float* dz4) {
+                                                       float* df, float* dz4, const float* loss_rows, ufnd_step_state* st_loss) {
   __shared__ float df_lds[32];
   __shared__ f32x4 part[4][NI][64];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -695,6 +736,7 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(const float* dlog, const 
     for (int q = 0; q < 4; ++q) o[q] = a[q] * gelu_grad_f(z[q]) * dm[q];
     st4(dz4 + (size_t)row * H + col, o);
   }
+  if (loss_rows && row == 0) ce_mean_block(loss_rows, B, st_loss);      // (block-uniform)
 }
 
 // NODE / bypass parameter gradients.  blocks [0,TK): gate tk (+ its threshold); [TK,TK+2): bypass
@@ -703,7 +745,12 @@ __global__ __launch_bounds__(256) void node_param_kernel(const float* df, const 
                                                          const float* alpha, const float* fs, int B, int H, int trees,
                                                          int depth, float node_p, const ufnd_step_state* st,
                                                          float* g_gates, float* g_thresh, float* g_leaf, float* g_bw,
-                                                         float* g_bb, float* part, int R) {
+                                                         float* g_bb, float* part, int R, GateRows gr) {
+  if (gr.first > 0 && (int)blockIdx.x >= gr.first) {
+    const int e = blockIdx.x - gr.first;
+    gate_param_rows_block(gr.evid, gr.dout, B, H, gr.p, gr.g, e % 3, e / 3);
+    return;
+  }
   __shared__ float sh[4];
   const int TK = trees * depth, blk = blockIdx.x;
   if (part) {
@@ -997,10 +1044,11 @@ extern "C" float* ufnd_clf_input_panel(const ufnd_dims* d, float* ws, int B, int
   return w.xin;
 }
 
-extern "C" int ufnd_fusion_forward(const ufnd_dims* d, const ufnd_fusion_params* p, const float* text,
-                                   const float* audio, const float* visual, const float* temporal, const float* gnn,
-                                   int B, int train, float* workspace, float* fused, int ld_fused, float* logits,
-                                   float* forensic, const ufnd_step_state* state, void* stream_) {
+namespace {
+int fusion_forward_impl(const ufnd_dims* d, const ufnd_fusion_params* p, const float* text,
+                        const float* audio, const float* visual, const float* temporal, const float* gnn,
+                        int B, int train, float* workspace, float* fused, int ld_fused, float* logits,
+                        float* forensic, const ufnd_step_state* state, void* stream_, const ClfPrep* prep_in) {
   TRY(check_dims(d, B));
   UFND_REQUIRE(p && text && audio && visual && temporal && workspace && fused && forensic && state, "fusion_forward: null argument");
   UFND_REQUIRE(gnn || d->gnn_dim == 0, "fusion_forward: gnn_feat is required when dims.gnn_dim > 0 (fuse_mlp then expects the 16*hidden concat, "
@@ -1041,9 +1089,12 @@ extern "C" int ufnd_fusion_forward(const ufnd_dims* d, const ufnd_fusion_params*
   //    4..14 (:44-54,172-178): one row kernel
   EvPtrs ev;
   for (int b = 0; b < 3; ++b) { ev.w0[b] = p->ev0_w[b]; ev.b0[b] = p->ev0_b[b]; ev.w2[b] = p->ev2_w[b]; ev.b2[b] = p->ev2_b[b]; }
-  if (H == 256) hipLaunchKernelGGL((coattn_pairs_wg_kernel<1>), dim3(B), blk, 0, stream, w.cat, (const float*)w.qkv, w.gate, B, H, w.s, ev, w.evid, forensic);
-  else if (H == 512) hipLaunchKernelGGL((coattn_pairs_wg_kernel<2>), dim3(B), blk, 0, stream, w.cat, (const float*)w.qkv, w.gate, B, H, w.s, ev, w.evid, forensic);
-  else hipLaunchKernelGGL((coattn_pairs_wg_kernel<4>), dim3(B), blk, 0, stream, w.cat, (const float*)w.qkv, w.gate, B, H, w.s, ev, w.evid, forensic);
+  ClfPrep prep{};
+  if (prep_in) prep = *prep_in;               // (fused head step: + B + trees * depth blocks preparing the classifier's input)
+  const dim3 cgrid(B + prep.blocks);
+  if (H == 256) hipLaunchKernelGGL((coattn_pairs_wg_kernel<1>), cgrid, blk, 0, stream, w.cat, (const float*)w.qkv, w.gate, B, H, w.s, ev, w.evid, forensic, prep);
+  else if (H == 512) hipLaunchKernelGGL((coattn_pairs_wg_kernel<2>), cgrid, blk, 0, stream, w.cat, (const float*)w.qkv, w.gate, B, H, w.s, ev, w.evid, forensic, prep);
+  else hipLaunchKernelGGL((coattn_pairs_wg_kernel<4>), cgrid, blk, 0, stream, w.cat, (const float*)w.qkv, w.gate, B, H, w.s, ev, w.evid, forensic, prep);
   UFND_CHECK_LAUNCH();
   // 4. fuse_mlp.0: (B,16H) x (2H,16H)^T, split-K then bias+GELU(+dropout)             (:122-124)
   {
@@ -1067,6 +1118,14 @@ extern "C" int ufnd_fusion_forward(const ufnd_dims* d, const ufnd_fusion_params*
     UFND_CHECK_LAUNCH();
   }
   return UFND_OK;
+}
+}  // namespace
+
+extern "C" int ufnd_fusion_forward(const ufnd_dims* d, const ufnd_fusion_params* p, const float* text,
+                                   const float* audio, const float* visual, const float* temporal, const float* gnn,
+                                   int B, int train, float* workspace, float* fused, int ld_fused, float* logits,
+                                   float* forensic, const ufnd_step_state* state, void* stream_) {
+  return fusion_forward_impl(d, p, text, audio, visual, temporal, gnn, B, train, workspace, fused, ld_fused, logits, forensic, state, stream_, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1121,11 +1180,24 @@ int clf_tn(const ufnd_dims& d, const ClfFactors& f, const ufnd_clf_params* g, in
 }
 }  // namespace
 
-extern "C" int ufnd_fusion_backward_phase(const ufnd_dims* d, const ufnd_fusion_params* p, const ufnd_fusion_params* g,
-                                          const float* text, const float* audio, const float* visual, const float* temporal,
-                                          const float* gnn, int B, int train, float* workspace, const float* d_fused,
-                                          int ld_dfused, const float* d_logits, const ufnd_step_state* state, void* stream_,
-                                          void* side_stream_, int join, int phase) {
+namespace {
+// The classifier's parameter-gradient launch, handed to the fusion backward by the fused head step: it is issued there together with
+// the evidence-gate parameter gradients, as ONE launch (node_param_kernel's blocks, then gate_param_rows' blocks).
+struct NodeParamJob {
+  const float *df, *dlog, *hh, *alpha, *fs;
+  int trees, depth;
+  float node_p;
+  float *g_gates, *g_thresh, *g_leaf, *g_bw, *g_bb;
+};
+struct FusedBwd {
+  bool dz2_ready;             // the classifier's last dX product has written dZ2 (activation derivative and mask applied): no act_bwd launch
+  const NodeParamJob* np;     // non-null: see above (B <= 64 only)
+};
+int fusion_backward_impl(const ufnd_dims* d, const ufnd_fusion_params* p, const ufnd_fusion_params* g,
+                         const float* text, const float* audio, const float* visual, const float* temporal,
+                         const float* gnn, int B, int train, float* workspace, const float* d_fused,
+                         int ld_dfused, const float* d_logits, const ufnd_step_state* state, void* stream_,
+                         void* side_stream_, int join, int phase, const FusedBwd* fo) {
   TRY(check_dims(d, B));
   // (factor form of the data-parallel exchange: the Linear dW / db products are left to ufnd_head_linear_grads_from_factors)
   const bool linear = !(phase & UFND_BWD_NO_LINEAR_GRADS);
@@ -1133,7 +1205,9 @@ extern "C" int ufnd_fusion_backward_phase(const ufnd_dims* d, const ufnd_fusion_
   UFND_REQUIRE(phase == UFND_BWD_ALL || phase == UFND_BWD_FUSE_MLP || phase == UFND_BWD_REST, "fusion_backward: phase=%d", phase);
   const bool do_head = phase != UFND_BWD_REST, do_rest = phase != UFND_BWD_FUSE_MLP;
   UFND_REQUIRE(p && g && text && audio && visual && temporal && (gnn || (d && d->gnn_dim == 0)) && workspace && state, "fusion_backward: null argument");
-  UFND_REQUIRE(!do_head || d_fused || d_logits, "fusion_backward: no incoming gradient");
+  const bool dz2_ready = fo && fo->dz2_ready;
+  UFND_REQUIRE(!do_head || d_fused || d_logits || dz2_ready, "fusion_backward: no incoming gradient");
+  UFND_REQUIRE(!dz2_ready || !d_logits, "fusion_backward: a fused dZ2 and an aux-head gradient are exclusive");
   hipStream_t stream = (hipStream_t)stream_;
   const ForkJoin fj{stream, (hipStream_t)side_stream_};
   const int H = d->hidden;
@@ -1154,6 +1228,7 @@ extern "C" int ufnd_fusion_backward_phase(const ufnd_dims* d, const ufnd_fusion_
     UFND_CHECK_LAUNCH();
   }
   // dZ2 = (d_fused + d_logits Wc) * gelu'(Z2) * mask
+  if (!dz2_ready)
   hipLaunchKernelGGL(act_bwd_kernel, dim3(ufnd_cdiv(B * H, 256)), blk, 0, stream, d_fused, ld_dfused, d_logits,
                      (const float*)p->cls_w, (const float*)w.z2, w.dz2, B, H, drop, LAYER_FUSE3, state);
   UFND_CHECK_LAUNCH();
@@ -1199,7 +1274,14 @@ extern "C" int ufnd_fusion_backward_phase(const ufnd_dims* d, const ufnd_fusion_
     }
     fj.fork(2);   // dout, dqkv, dg are ready
     const int S = param_slices(B);
-    if (B <= 64) {
+    if (B <= 64 && fo && fo->np) {
+      // fused head step: the classifier's parameter gradients (ready since node_bwd) and these in ONE launch
+      const NodeParamJob& j = *fo->np;
+      const int nodeb = j.trees * j.depth + 2 + ufnd_cdiv(j.trees * (1 << j.depth) * 2, 8);
+      GateRows gr{(const float*)w.evid, (const float*)w.dout, ep, eg, nodeb};
+      hipLaunchKernelGGL(node_param_kernel, dim3(nodeb + 3 * ufnd_cdiv(H, 4)), dim3(256), 0, fj.dw(), j.df, j.dlog, j.hh, j.alpha, j.fs, B, H, j.trees, j.depth,
+                         j.node_p, state, j.g_gates, j.g_thresh, j.g_leaf, j.g_bw, j.g_bb, (float*)nullptr, B, gr);
+    } else if (B <= 64) {
       hipLaunchKernelGGL(gate_param_rows_kernel, dim3(3, ufnd_cdiv(H, 4)), dim3(256), 0, fj.dw(), (const float*)w.evid, (const float*)w.dout, B, H, ep, eg);
     } else {
       hipLaunchKernelGGL(gate_param_kernel, dim3(3, S), dim3(H > 512 ? 512 : H), 0, fj.dw(), (const float*)w.evid,
@@ -1229,6 +1311,16 @@ extern "C" int ufnd_fusion_backward_phase(const ufnd_dims* d, const ufnd_fusion_
   }  // do_rest
   if (join) fj.join(4);
   return UFND_OK;
+}
+}  // namespace
+
+extern "C" int ufnd_fusion_backward_phase(const ufnd_dims* d, const ufnd_fusion_params* p, const ufnd_fusion_params* g,
+                                          const float* text, const float* audio, const float* visual, const float* temporal,
+                                          const float* gnn, int B, int train, float* workspace, const float* d_fused,
+                                          int ld_dfused, const float* d_logits, const ufnd_step_state* state, void* stream_,
+                                          void* side_stream_, int join, int phase) {
+  return fusion_backward_impl(d, p, g, text, audio, visual, temporal, gnn, B, train, workspace, d_fused, ld_dfused, d_logits, state, stream_,
+                              side_stream_, join, phase, nullptr);
 }
 
 extern "C" int ufnd_fusion_backward(const ufnd_dims* d, const ufnd_fusion_params* p, const ufnd_fusion_params* g,
@@ -1271,9 +1363,15 @@ extern "C" int ufnd_fusion_feature_grads(const ufnd_dims* d, const ufnd_fusion_p
   return launch_nn(n, k, state, (hipStream_t)stream_);
 }
 
-extern "C" int ufnd_classifier_forward(const ufnd_dims* d, const ufnd_clf_params* p, const float* fused, int ld_fused,
-                                       const float* aux, int B, int train, float* workspace, float* logits,
-                                       float* probs, const ufnd_step_state* state, void* stream_) {
+namespace {
+struct FusedClfFwd {
+  bool prep_done;             // the input panel's aux columns and alpha were written by the co-attention launch
+  const int64_t* labels;      // non-null: node_head also writes this row's CE term (workspace) and d_logits
+  float* d_logits;
+};
+int classifier_forward_impl(const ufnd_dims* d, const ufnd_clf_params* p, const float* fused, int ld_fused,
+                            const float* aux, int B, int train, float* workspace, float* logits,
+                            float* probs, const ufnd_step_state* state, void* stream_, const FusedClfFwd* fo) {
   TRY(check_dims(d, B));
   UFND_REQUIRE(p && fused && workspace && logits && probs && state, "classifier_forward: null argument");
   UFND_REQUIRE((d->aux_dim == 0) == (aux == nullptr), "classifier_forward: aux must be given iff aux_dim > 0 (pre.0 is %d wide)",
@@ -1285,9 +1383,11 @@ extern "C" int ufnd_classifier_forward(const ufnd_dims* d, const ufnd_clf_params
   const float drop = train ? d->clf_dropout : 0.0f;
   const dim3 rows(ufnd_cdiv(B, 4)), blk(256);
 
-  hipLaunchKernelGGL(clf_prep_kernel, dim3(B + d->trees * d->depth), blk, 0, stream, fused, ld_fused, aux, d->aux_dim, w.xin, w.ldx, B, H,
-                     fused != w.xin ? 1 : 0, (const float*)p->gates, w.alpha);
-  UFND_CHECK_LAUNCH();
+  if (!(fo && fo->prep_done)) {
+    const ClfPrep prep{fused, aux, (const float*)p->gates, w.xin, w.alpha, ld_fused, d->aux_dim, w.ldx, fused != w.xin ? 1 : 0, B + d->trees * d->depth};
+    hipLaunchKernelGGL(clf_prep_kernel, dim3(prep.blocks), blk, 0, stream, prep, B, H);
+    UFND_CHECK_LAUNCH();
+  }
   {  // pre.0 / pre.3 + GELU(+dropout)                                    deep_truth_classifier.py:121-128
     NtProb a{w.xin, p->pre0_w, p->pre0_b, w.h3, w.z3, B, H, H + d->aux_dim, w.ldx, H + d->aux_dim, H, H, 1, drop, LAYER_PRE0, 1};
     TRY(launch_nt(&a, 1, state, stream));
@@ -1297,15 +1397,29 @@ extern "C" int ufnd_classifier_forward(const ufnd_dims* d, const ufnd_clf_params
   NI_DISPATCH(H, node_head_kernel, dim3(B), blk, stream, (const float*)w.hh, (const float*)w.alpha, (const float*)p->thresh,
               (const float*)p->leaf, (const float*)p->tau, (const float*)p->bypass_w, (const float*)p->bypass_b,
               (const float*)p->temperature, B, H, d->trees, d->depth, train ? d->node_dropout : 0.0f, state, w.fs, logits,
-              probs);
+              probs, fo ? fo->labels : (const int64_t*)nullptr, w.lrow, fo ? fo->d_logits : (float*)nullptr);
   UFND_CHECK_LAUNCH();
   return UFND_OK;
 }
+}  // namespace
 
-extern "C" int ufnd_classifier_backward_ex(const ufnd_dims* d, const ufnd_clf_params* p, const ufnd_clf_params* g, int B,
-                                           int train, float* workspace, const float* d_logits, float* d_fused,
-                                           int ld_dfused, const ufnd_step_state* state, void* stream_, void* side_stream_,
-                                           int join, int flags) {
+extern "C" int ufnd_classifier_forward(const ufnd_dims* d, const ufnd_clf_params* p, const float* fused, int ld_fused,
+                                       const float* aux, int B, int train, float* workspace, float* logits,
+                                       float* probs, const ufnd_step_state* state, void* stream_) {
+  return classifier_forward_impl(d, p, fused, ld_fused, aux, B, train, workspace, logits, probs, state, stream_, nullptr);
+}
+
+namespace {
+struct FusedClfBwd {
+  ufnd_step_state* loss_state;   // non-null: block 0 of node_bwd writes the batch-mean loss from the CE rows node_head left
+  const float* next_z;           // non-null: the last dX product multiplies by gelu'(next_z) and the dropout mask of the layer that
+  float next_drop;               //           produced `fused` (fuse_mlp.3) and writes dZ2 (B, hidden) into d_fused -- act_bwd's job
+  bool defer_node_param;         // the parameter-gradient launch is left to the fusion backward (NodeParamJob)
+};
+int classifier_backward_impl(const ufnd_dims* d, const ufnd_clf_params* p, const ufnd_clf_params* g, int B,
+                             int train, float* workspace, const float* d_logits, float* d_fused,
+                             int ld_dfused, const ufnd_step_state* state, void* stream_, void* side_stream_,
+                             int join, int flags, const FusedClfBwd* fo) {
   TRY(check_dims(d, B));
   UFND_REQUIRE((flags & ~UFND_BWD_NO_LINEAR_GRADS) == 0, "classifier_backward: flags=%d", flags);
   UFND_REQUIRE(p && g && workspace && d_logits && d_fused && state, "classifier_backward: null argument");
@@ -1319,16 +1433,17 @@ extern "C" int ufnd_classifier_backward_ex(const ufnd_dims* d, const ufnd_clf_pa
 
   NI_DISPATCH(H, node_bwd_kernel, dim3(B), blk, stream, d_logits, (const float*)w.fs, (const float*)w.alpha,
               (const float*)p->leaf, (const float*)p->tau, (const float*)p->bypass_w, (const float*)w.z4, B, H, d->trees,
-              d->depth, ndrop, drop, state, w.df, w.dz4);
+              d->depth, ndrop, drop, state, w.df, w.dz4, fo && fo->loss_state ? (const float*)w.lrow : (const float*)nullptr,
+              fo ? fo->loss_state : (ufnd_step_state*)nullptr);
   UFND_CHECK_LAUNCH();
   fj.fork(5);   // df, dz4 are ready
-  {
+  if (!(fo && fo->defer_node_param)) {
     const int S = param_slices(B);
     // (one-pass form: the leaf tables take ceil(2 trees leaves / 8) workgroups of their own; row-sliced form: one per slice)
     const int leaf_blocks = S > 1 ? 1 : ufnd_cdiv(d->trees * (1 << d->depth) * 2, 8);
     hipLaunchKernelGGL(node_param_kernel, dim3(d->trees * d->depth + 2 + leaf_blocks, S), blk, 0, fj.dw(), (const float*)w.df, d_logits,
                        (const float*)w.hh, (const float*)w.alpha, (const float*)w.fs, B, H, d->trees, d->depth, ndrop, state,
-                       g->gates, g->thresh, g->leaf, g->bypass_w, g->bypass_b, S > 1 ? w.npart : (float*)nullptr, (B + S - 1) / S);
+                       g->gates, g->thresh, g->leaf, g->bypass_w, g->bypass_b, S > 1 ? w.npart : (float*)nullptr, (B + S - 1) / S, GateRows{});
     UFND_CHECK_LAUNCH();
     if (S > 1) {
       hipLaunchKernelGGL(node_param_finish_kernel, dim3(d->trees * d->depth + 3), blk, 0, fj.dw(), (const float*)w.npart, S,
@@ -1347,10 +1462,25 @@ extern "C" int ufnd_classifier_backward_ex(const ufnd_dims* d, const ufnd_clf_pa
     clf_tn(*d, ClfFactors{w.dz4, w.h3, w.dz3, w.xin, w.ldx}, g, B, t);
     if (!(flags & UFND_BWD_NO_LINEAR_GRADS)) TRY(launch_tn(t, 2, fj.dw()));
     NnProb n{w.dz3, p->pre0_w, d_fused, nullptr, nullptr, B, H, H, H, H + d->aux_dim, ld_dfused, 0, 0, 0.0f, 0, 0, 1};
+    if (fo && fo->next_z) {      // dZ2 = d_fused gelu'(Z2) mask, the expression of act_bwd_kernel, in this product's epilogue
+      n.actZ = fo->next_z;
+      n.ldz = H;
+      n.drop_p = fo->next_drop;
+      n.drop_layer = LAYER_FUSE3;
+      n.drop_ld = H;
+    }
     TRY(launch_nn(&n, 1, state, stream));
   }
   if (join) fj.join(7);
   return UFND_OK;
+}
+}  // namespace
+
+extern "C" int ufnd_classifier_backward_ex(const ufnd_dims* d, const ufnd_clf_params* p, const ufnd_clf_params* g, int B,
+                                           int train, float* workspace, const float* d_logits, float* d_fused,
+                                           int ld_dfused, const ufnd_step_state* state, void* stream_, void* side_stream_,
+                                           int join, int flags) {
+  return classifier_backward_impl(d, p, g, B, train, workspace, d_logits, d_fused, ld_dfused, state, stream_, side_stream_, join, flags, nullptr);
 }
 
 extern "C" int ufnd_classifier_backward(const ufnd_dims* d, const ufnd_clf_params* p, const ufnd_clf_params* g, int B,
@@ -1462,6 +1592,55 @@ extern "C" int ufnd_head_linear_grads_from_factors(const ufnd_dims* d, const ufn
     TRY(launch_tn(tn, n, (hipStream_t)stream_));
   }
   return UFND_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The head's train step as TWO entries over both modules (round 4): the same kernels and the same arithmetic as
+//   ufnd_fusion_forward -> ufnd_classifier_forward -> ufnd_softmax_ce -> ufnd_classifier_backward -> ufnd_fusion_backward_phase
+// (forensic_trainer.py:285-291), with the launches that exist only because those are five calls folded into their neighbours:
+//   * the classifier's input preparation (aux columns, alpha = softmax(gates)) rides as extra blocks of the co-attention row kernel;
+//   * node_head writes each row's CE term and d_logits, block 0 of node_bwd averages the rows (softmax_ce's order: same bits);
+//   * the classifier's last dX product applies gelu'(Z2) and fuse_mlp.3's dropout mask in its epilogue and writes dZ2 (act_bwd);
+//   * (whole backward only, B <= 64) the classifier's and the evidence gates' parameter gradients are one launch.
+// 26 -> 22 launches per step at B = 32; logits, loss and every gradient bit-identical to the five-call sequence (test).
+// ------------------------------------------------------------------------------------------------
+extern "C" int ufnd_head_forward_loss(const ufnd_dims* d, const ufnd_fusion_params* fp, const ufnd_clf_params* cp, const ufnd_head_io* io, int B,
+                                      int train, ufnd_step_state* state, void* stream_) {
+  TRY(check_dims(d, B));
+  UFND_REQUIRE(fp && cp && io && state, "head_forward_loss: null argument");
+  UFND_REQUIRE(io->fusion_workspace && io->clf_workspace && io->logits && io->probs && io->forensic && io->labels && io->d_logits,
+               "head_forward_loss: null buffer");
+  UFND_REQUIRE((d->aux_dim == 0) == (io->aux == nullptr), "head_forward_loss: aux must be given iff aux_dim > 0");
+  const ClfWs c = carve_clf(*d, B, io->clf_workspace);
+  const ClfPrep prep{c.xin, io->aux, (const float*)cp->gates, c.xin, c.alpha, c.ldx, d->aux_dim, c.ldx, 0, B + d->trees * d->depth};
+  TRY(fusion_forward_impl(d, fp, io->text, io->audio, io->visual, io->temporal, io->gnn, B, train, io->fusion_workspace, c.xin, c.ldx, nullptr,
+                          io->forensic, state, stream_, &prep));
+  const FusedClfFwd fo{true, io->labels, io->d_logits};
+  return classifier_forward_impl(d, cp, c.xin, c.ldx, io->aux, B, train, io->clf_workspace, io->logits, io->probs, state, stream_, &fo);
+}
+
+extern "C" int ufnd_head_backward(const ufnd_dims* d, const ufnd_fusion_params* fp, const ufnd_fusion_params* fg, const ufnd_clf_params* cp,
+                                  const ufnd_clf_params* cg, const ufnd_head_io* io, int B, int train, ufnd_step_state* state, void* stream_,
+                                  void* side_stream_, int join, int phase) {
+  TRY(check_dims(d, B));
+  UFND_REQUIRE(fp && fg && cp && cg && io && state && io->fusion_workspace && io->clf_workspace && io->d_logits, "head_backward: null argument");
+  const int flags = phase & UFND_BWD_NO_LINEAR_GRADS, ph = phase & ~UFND_BWD_NO_LINEAR_GRADS;
+  UFND_REQUIRE(ph == UFND_BWD_ALL || ph == UFND_BWD_FUSE_MLP || ph == UFND_BWD_REST, "head_backward: phase=%d", phase);
+  const FusionWs w = carve_fusion(*d, B, io->fusion_workspace);
+  const ClfWs c = carve_clf(*d, B, io->clf_workspace);
+  const float fdrop = train ? d->fusion_dropout : 0.0f;
+  // the parameter-gradient launches merge only when the whole backward is one call (a phased caller starts reducing the classifier's
+  // gradients after the first phase: they must be complete there)
+  const bool merge_params = ph == UFND_BWD_ALL && B <= 64;
+  const NodeParamJob np{c.df, io->d_logits, c.hh, c.alpha, c.fs, d->trees, d->depth, train ? d->node_dropout : 0.0f,
+                        cg->gates, cg->thresh, cg->leaf, cg->bypass_w, cg->bypass_b};
+  if (ph != UFND_BWD_REST) {
+    const FusedClfBwd fo{state, w.z2, fdrop, merge_params};
+    TRY(classifier_backward_impl(d, cp, cg, B, train, io->clf_workspace, io->d_logits, w.dz2, d->hidden, state, stream_, side_stream_, 0, flags, &fo));
+  }
+  const FusedBwd fb{true, merge_params ? &np : (const NodeParamJob*)nullptr};
+  return fusion_backward_impl(d, fp, fg, io->text, io->audio, io->visual, io->temporal, io->gnn, B, train, io->fusion_workspace, nullptr, d->hidden,
+                              nullptr, state, stream_, side_stream_, join, phase, &fb);
 }
 
 extern "C" int ufnd_softmax_ce_weighted(const float* logits, const int64_t* labels, int B, float w0, float w1, float label_smoothing,

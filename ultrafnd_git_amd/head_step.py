@@ -26,6 +26,9 @@ class HeadStep:
         self.step_bufs: Dict[Tuple[int, bool, int], dict] = {}
         # the head's fwd/bwd as a graph (default with use_graph) or eager with the dW side stream
         self.head_graph = bool(cfg.use_graph and cfg.head_graph)
+        # the two-call fused form of the step (ufnd_head_forward_loss / ufnd_head_backward: 22 launches instead of 26, same bits) whenever
+        # the criterion is the plain mean CE; the weighted / label-smoothed criterion keeps the five module-level calls
+        self.fused_entries = not (cfg.label_smoothing > 0.0 or cfg.class_weighting) and bool(getattr(cfg, "fused_head", True))
         self._dw_stream: Optional[torch.cuda.Stream] = None
         self._iota: Optional[torch.Tensor] = None
 
@@ -108,9 +111,23 @@ class HeadStep:
                      [(src.data_ptr(), dst, src[0].numel() * src.element_size(), src.shape[0]) for src, dst in pairs], "ufnd_gather_rows")
 
     # ------------------------------------------------------------------ launches
+    def _io(self, b: dict) -> "L.HeadIO":
+        if "io" not in b:
+            io = L.HeadIO()
+            io.text, io.audio, io.visual, io.temporal = (b[k].data_ptr() for k in ("text", "audio", "visual", "temporal"))
+            io.gnn, io.aux, io.labels = b["gnn"].data_ptr(), b["aux"].data_ptr(), b["label"].data_ptr()
+            io.fusion_workspace, io.clf_workspace = b["fws"].data_ptr(), b["cws"].data_ptr()
+            io.logits, io.probs, io.forensic, io.d_logits = (b[k].data_ptr() for k in ("logits", "probs", "forensic", "dlogits"))
+            b["io"] = io
+        return b["io"]
+
     def enqueue_forward(self, b: dict, B: int, train: bool, with_loss_grad: bool) -> None:
         lib, s, st = L.lib(), L.stream_ptr(self.device), self.optim.state.ptr
         d = b["dims"]
+        if self.fused_entries and train and with_loss_grad:
+            L.check(lib.ufnd_head_forward_loss(C.byref(d), C.byref(self.fusion.param_table()), C.byref(self.clf.param_table()), C.byref(self._io(b)),
+                                               B, 1, st, s), "ufnd_head_forward_loss")
+            return
         L.check(lib.ufnd_fusion_forward(C.byref(d), C.byref(self.fusion.param_table()), b["text"].data_ptr(),
                                         b["audio"].data_ptr(), b["visual"].data_ptr(), b["temporal"].data_ptr(),
                                         b["gnn"].data_ptr(), B, int(train), b["fws"].data_ptr(), b["xin"], b["ldx"], None,
@@ -133,6 +150,16 @@ class HeadStep:
         lib, s, st = L.lib(), L.stream_ptr(self.device), self.optim.state.ptr
         d = b["dims"]
         skip = 0 if linear_grads else L.BWD_NO_LINEAR_GRADS
+        if self.fused_entries:
+            side_f = None
+            if not self.head_graph:
+                if self._dw_stream is None:
+                    self._dw_stream = torch.cuda.Stream(device=self.device)
+                side_f = self._dw_stream.cuda_stream
+            L.check(lib.ufnd_head_backward(C.byref(d), C.byref(self.fusion.param_table()), C.byref(self.fusion.grad_table()), C.byref(self.clf.param_table()),
+                                           C.byref(self.clf.grad_table()), C.byref(self._io(b)), B, 1, st, s, side_f, 1,
+                                           (L.BWD_ALL, L.BWD_FUSE_MLP, L.BWD_REST)[part] | skip), "ufnd_head_backward")
+            return
         # Eager launches: dW / parameter-gradient kernels run beside the dX chain on a second stream (joined
         # at the end).  Inside a captured hipGraph the fork/join costs more than it hides (ROCm 7 replays
         # multi-branch graphs almost serially -- measured), so the graph keeps one stream.

@@ -84,6 +84,7 @@ class TrainConfig:
     encoder_lookahead: int = 4
     # experiments / diagnostics that used to be environment variables
     head_graph: bool = True        # False: the head's forward / backward eagerly (dW kernels on a side stream) even with use_graph
+    fused_head: bool = True        # the head's forward + CE and its backward as two C-ABI calls (22 launches, same bits); False: the five module-level calls (26)
     # the loader rotates a small fixed set of device input buffers (bench.py: four): encoder graphs read them in place, one graph
     # per buffer set (pipeline.py).  False: every batch that is not one of the trainer's own group buffers is staged.
     persistent_inputs: bool = False
