@@ -408,7 +408,7 @@ def main():
                                                     "bucketed all-reduce overlapped with backward"),
                               "timing": {"what": f"median of {len(blocks)} blocks of {args.steps} steps",
                                          "ms_per_step_blocks": [round(x / args.steps * 1e3, 4) for x in blocks]},
-                              "roofline": {"bound": "hbm", "kernel": "whole head step (22 launches; AdamW + grad-norm + the three fuse_mlp.0 GEMMs move 90 % of the bytes)",
+                              "roofline": {"bound": "hbm", "kernel": "whole head step (21 launches; AdamW + grad-norm + the three fuse_mlp.0 GEMMs move 90 % of the bytes)",
                                            "achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 4),
                                            "algorithmic_MB_per_step": round(11 * 4 * P / 1e6, 1), "traffic": None}}))
         if dist.is_initialized():

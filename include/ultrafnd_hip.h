@@ -213,7 +213,7 @@ int ufnd_head_linear_grads_from_factors(const ufnd_dims* d, const ufnd_fusion_pa
  * with the same kernels and arithmetic as ufnd_fusion_forward -> ufnd_classifier_forward -> ufnd_softmax_ce ->
  * ufnd_classifier_backward -> ufnd_fusion_backward_phase, minus the launches that exist only because those are five calls
  * (classifier input preparation, the CE kernel, the activation backward between the modules, one of the two parameter-gradient
- * launches): 26 -> 22 launches per step at B = 32.  Logits, probabilities, forensic scalars, state->loss, d_logits and every
+ * launches, the classifier's own weight-gradient launch): 26 -> 21 launches per step at B = 32.  Logits, probabilities, forensic scalars, state->loss, d_logits and every
  * gradient are bit-identical to the five-call sequence.  The fusion writes `fused` straight into the classifier's input panel;
  * the aux head (fusion logits) is not evaluated.  Plain mean CE only (the weighted / label-smoothed criterion keeps the
  * five-call sequence).  `phase` as in ufnd_fusion_backward_phase (UFND_BWD_FUSE_MLP includes the classifier's backward).

@@ -472,6 +472,7 @@ __global__ __launch_bounds__(256) void nn16_kernel(const NnArgs args) {
 struct TnArgs {
   TnProb p[UFND_GEMM_MAX_PROB];
   int begin[UFND_GEMM_MAX_PROB + 1];  // in wave-tiles
+  int vec[UFND_GEMM_MAX_PROB];        // per-problem vector width (tn_kernel<-1>)
   int nprob;
 };
 
@@ -482,16 +483,9 @@ struct TnArgs {
 // grouped launch, 72 us for the classifier's 272 tiles); this form has 4 x the waves and a quarter of the chain.
 // SEG = 1: the batch rows come in segments (TnProb::seg_rows; the factor form of the data-parallel exchange) -- its own
 // instantiation, so that the one-panel kernels keep their code.
-template <int VEC, int MSPLIT = 0, int SEG = 0>
-__global__ __launch_bounds__(256) void tn_kernel(const TnArgs args) {
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-  const int tile = MSPLIT ? (int)blockIdx.x : blockIdx.x * 4 + w;
-  if (tile >= args.begin[args.nprob]) return;
-  int pi = 0;
-  for (int q = 1; q < args.nprob; ++q)
-    if (tile >= args.begin[q]) pi = q;
-  const TnProb& P = args.p[pi];
-  const int local = tile - args.begin[pi];
+template <int VEC, int MSPLIT, int SEG>
+__device__ __forceinline__ void tn_tile(const TnProb& P, int local, int w, int lane) {
+  const int j = lane & 31, h = lane >> 5;
   const int strips = (P.K + 32 * VEC - 1) / (32 * VEC);
   const int strip = local % strips;
   const int n0 = (local / strips) << 5;
@@ -607,6 +601,26 @@ __global__ __launch_bounds__(256) void tn_kernel(const TnArgs args) {
     const float s = dbsum + __shfl_xor(dbsum, 32, 64);
     if (h == 0) P.db[n0 + j] = s;
   }
+  }
+}
+// VEC < 0: every problem with its OWN vector width (TnArgs::vec: 4 where its operands allow 16-byte accesses, else 2) -- a
+// (hidden + aux)-wide problem then no longer puts a whole grouped launch on 8-byte accesses (one-wave-per-tile form only).
+template <int VEC, int MSPLIT = 0, int SEG = 0>
+__global__ __launch_bounds__(256) void tn_kernel(const TnArgs args) {
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tile = MSPLIT ? (int)blockIdx.x : blockIdx.x * 4 + w;
+  if (tile >= args.begin[args.nprob]) return;
+  int pi = 0;
+  for (int q = 1; q < args.nprob; ++q)
+    if (tile >= args.begin[q]) pi = q;
+  const TnProb& P = args.p[pi];
+  const int local = tile - args.begin[pi];
+  if constexpr (VEC > 0) {
+    tn_tile<VEC, MSPLIT, SEG>(P, local, w, lane);
+  } else {
+    static_assert(VEC > 0 || MSPLIT == 0, "per-problem widths: one wave per tile");
+    if (args.vec[pi] == 4) tn_tile<4, 0, SEG>(P, local, w, lane);      // (wave-uniform)
+    else tn_tile<2, 0, SEG>(P, local, w, lane);
   }
 }
 
@@ -766,21 +780,28 @@ int launch_tn(const TnProb* probs, int nprob, hipStream_t stream) {
   // head-only step 0.254-0.256 -> 0.264 ms; a form whose accumulator v owns 32 CONSECUTIVE columns (4-byte accesses) and stores each
   // accumulator as soon as it is complete, so that the store phase starts under the matrix phase: 182 VGPRs (two waves per SIMD instead
   // of three), 24.7 -> 31.0 us for the launch (profiles/r04_head_tn_small.txt).  The 32 x 128 form with 16-B accesses stays.
+  int minM = a.p[0].M;
+  for (int i = 1; i < nprob; ++i) minM = a.p[i].M < minM ? a.p[i].M : minM;
+  // one wave per tile (small batches) and mixed alignments: each problem keeps its own width (the same tiles and bits it would
+  // have in a launch of its own)
+  const bool mixed = minM < 128 && !vec4 && nprob > 1;
   const int VEC = vec4 ? 4 : 2;
   int total = 0;
   for (int i = 0; i < nprob; ++i) {
+    const TnProb& q = a.p[i];
+    const bool q4 = q.K % 4 == 0 && q.ldx % 4 == 0 && q.ldw % 4 == 0 && ufnd_aligned(q.X, 16) && ufnd_aligned(q.dW, 16) && (!q.seg_rows || q.seg_x % 4 == 0);
+    a.vec[i] = mixed ? (q4 ? 4 : 2) : VEC;
     a.begin[i] = total;
-    total += (a.p[i].N / 32) * ufnd_cdiv(a.p[i].K, 32 * VEC);
+    total += (q.N / 32) * ufnd_cdiv(q.K, 32 * a.vec[i]);
   }
   a.begin[nprob] = total;
-  int minM = a.p[0].M;
-  for (int i = 1; i < nprob; ++i) minM = a.p[i].M < minM ? a.p[i].M : minM;
   if (seg) {              // gathered factors: the same two forms, rows addressed by segment
     if (minM >= 128) {
       if (vec4) hipLaunchKernelGGL((tn_kernel<4, 1, 1>), dim3(total), dim3(256), 0, stream, a);
       else hipLaunchKernelGGL((tn_kernel<2, 1, 1>), dim3(total), dim3(256), 0, stream, a);
     } else {
-      if (vec4) hipLaunchKernelGGL((tn_kernel<4, 0, 1>), dim3(ufnd_cdiv(total, 4)), dim3(256), 0, stream, a);
+      if (mixed) hipLaunchKernelGGL((tn_kernel<-1, 0, 1>), dim3(ufnd_cdiv(total, 4)), dim3(256), 0, stream, a);
+      else if (vec4) hipLaunchKernelGGL((tn_kernel<4, 0, 1>), dim3(ufnd_cdiv(total, 4)), dim3(256), 0, stream, a);
       else hipLaunchKernelGGL((tn_kernel<2, 0, 1>), dim3(ufnd_cdiv(total, 4)), dim3(256), 0, stream, a);
     }
   } else if (minM >= 128) {      // batch rows split over the four waves of a workgroup (one workgroup per tile)
@@ -788,7 +809,8 @@ int launch_tn(const TnProb* probs, int nprob, hipStream_t stream) {
     else hipLaunchKernelGGL((tn_kernel<2, 1>), dim3(total), dim3(256), 0, stream, a);
   } else {
     const int blocks = ufnd_cdiv(total, 4);
-    if (vec4) hipLaunchKernelGGL((tn_kernel<4>), dim3(blocks), dim3(256), 0, stream, a);
+    if (mixed) hipLaunchKernelGGL((tn_kernel<-1>), dim3(blocks), dim3(256), 0, stream, a);
+    else if (vec4) hipLaunchKernelGGL((tn_kernel<4>), dim3(blocks), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((tn_kernel<2>), dim3(blocks), dim3(256), 0, stream, a);
   }
   UFND_CHECK_LAUNCH();

@@ -1192,6 +1192,8 @@ struct NodeParamJob {
 struct FusedBwd {
   bool dz2_ready;             // the classifier's last dX product has written dZ2 (activation derivative and mask applied): no act_bwd launch
   const NodeParamJob* np;     // non-null: see above (B <= 64 only)
+  const TnProb* extra_tn;     // the classifier's two dW / db problems, to join this module's grouped launch (whole backward only)
+  int n_extra;
 };
 int fusion_backward_impl(const ufnd_dims* d, const ufnd_fusion_params* p, const ufnd_fusion_params* g,
                          const float* text, const float* audio, const float* visual, const float* temporal,
@@ -1307,6 +1309,8 @@ int fusion_backward_impl(const ufnd_dims* d, const ufnd_fusion_params* p, const 
   }
   // stacked q/k/v and projections: dW, db (the projections' inputs are data: no dX)
   ntn += fusion_tn_rest(*d, fusion_factors(w, B, H, text, audio, visual, temporal, gnn), g, B, tn + ntn);
+  if (fo && fo->extra_tn)
+    for (int i = 0; i < fo->n_extra; ++i) tn[ntn++] = fo->extra_tn[i];
   if (linear) TRY(launch_tn(tn, ntn, fj.dw()));
   }  // do_rest
   if (join) fj.join(4);
@@ -1415,6 +1419,7 @@ struct FusedClfBwd {
   const float* next_z;           // non-null: the last dX product multiplies by gelu'(next_z) and the dropout mask of the layer that
   float next_drop;               //           produced `fused` (fuse_mlp.3) and writes dZ2 (B, hidden) into d_fused -- act_bwd's job
   bool defer_node_param;         // the parameter-gradient launch is left to the fusion backward (NodeParamJob)
+  bool defer_tn;                 // ... and so are the two dW / db problems (FusedBwd::extra_tn)
 };
 int classifier_backward_impl(const ufnd_dims* d, const ufnd_clf_params* p, const ufnd_clf_params* g, int B,
                              int train, float* workspace, const float* d_logits, float* d_fused,
@@ -1460,7 +1465,7 @@ int classifier_backward_impl(const ufnd_dims* d, const ufnd_clf_params* p, const
     fj.fork(6);   // dz3 is ready
     TnProb t[2];
     clf_tn(*d, ClfFactors{w.dz4, w.h3, w.dz3, w.xin, w.ldx}, g, B, t);
-    if (!(flags & UFND_BWD_NO_LINEAR_GRADS)) TRY(launch_tn(t, 2, fj.dw()));
+    if (!(flags & UFND_BWD_NO_LINEAR_GRADS) && !(fo && fo->defer_tn)) TRY(launch_tn(t, 2, fj.dw()));
     NnProb n{w.dz3, p->pre0_w, d_fused, nullptr, nullptr, B, H, H, H, H + d->aux_dim, ld_dfused, 0, 0, 0.0f, 0, 0, 1};
     if (fo && fo->next_z) {      // dZ2 = d_fused gelu'(Z2) mask, the expression of act_bwd_kernel, in this product's epilogue
       n.actZ = fo->next_z;
@@ -1602,7 +1607,8 @@ extern "C" int ufnd_head_linear_grads_from_factors(const ufnd_dims* d, const ufn
 //   * node_head writes each row's CE term and d_logits, block 0 of node_bwd averages the rows (softmax_ce's order: same bits);
 //   * the classifier's last dX product applies gelu'(Z2) and fuse_mlp.3's dropout mask in its epilogue and writes dZ2 (act_bwd);
 //   * (whole backward only, B <= 64) the classifier's and the evidence gates' parameter gradients are one launch.
-// 26 -> 22 launches per step at B = 32; logits, loss and every gradient bit-identical to the five-call sequence (test).
+//   * (whole backward only, B < 128) the classifier's two weight-gradient problems join the fusion's grouped launch.
+// 26 -> 21 launches per step at B = 32; logits, loss and every gradient bit-identical to the five-call sequence (test).
 // ------------------------------------------------------------------------------------------------
 extern "C" int ufnd_head_forward_loss(const ufnd_dims* d, const ufnd_fusion_params* fp, const ufnd_clf_params* cp, const ufnd_head_io* io, int B,
                                       int train, ufnd_step_state* state, void* stream_) {
@@ -1634,11 +1640,15 @@ extern "C" int ufnd_head_backward(const ufnd_dims* d, const ufnd_fusion_params* 
   const bool merge_params = ph == UFND_BWD_ALL && B <= 64;
   const NodeParamJob np{c.df, io->d_logits, c.hh, c.alpha, c.fs, d->trees, d->depth, train ? d->node_dropout : 0.0f,
                         cg->gates, cg->thresh, cg->leaf, cg->bypass_w, cg->bypass_b};
+  // ... and so do the weight-gradient launches (tn_kernel keeps a vector width per problem: the (hidden + aux)-wide pre.0 does not slow the others)
+  const bool merge_tn = ph == UFND_BWD_ALL && B < 128 && !flags;
+  TnProb ctn[2];
+  clf_tn(*d, ClfFactors{c.dz4, c.h3, c.dz3, c.xin, c.ldx}, cg, B, ctn);
   if (ph != UFND_BWD_REST) {
-    const FusedClfBwd fo{state, w.z2, fdrop, merge_params};
+    const FusedClfBwd fo{state, w.z2, fdrop, merge_params, merge_tn};
     TRY(classifier_backward_impl(d, cp, cg, B, train, io->clf_workspace, io->d_logits, w.dz2, d->hidden, state, stream_, side_stream_, 0, flags, &fo));
   }
-  const FusedBwd fb{true, merge_params ? &np : (const NodeParamJob*)nullptr};
+  const FusedBwd fb{true, merge_params ? &np : (const NodeParamJob*)nullptr, merge_tn ? ctn : (const TnProb*)nullptr, merge_tn ? 2 : 0};
   return fusion_backward_impl(d, fp, fg, io->text, io->audio, io->visual, io->temporal, io->gnn, B, train, io->fusion_workspace, nullptr, d->hidden,
                               nullptr, state, stream_, side_stream_, join, phase, &fb);
 }
