@@ -354,3 +354,25 @@ def test_two_call_head_step_is_bit_identical_to_the_five_call_sequence(tmp_path,
     for key, got in res.items():
         for a, b in zip(got, ref):
             assert (torch.equal(a, b) if isinstance(a, torch.Tensor) else a == b), key
+
+
+@pytest.mark.parametrize("B", [32, 130])
+def test_forty_steps_twice_leave_the_same_bits(tmp_path, B):
+    """Run-to-run determinism over a long chain (dropout on, captured graphs, below and above the row-sliced parameter reductions): no kernel of
+    the step may depend on which workgroup finishes first -- every reduction has a fixed order and nothing is summed by atomics."""
+    res = []
+    for _ in range(2):
+        torch.manual_seed(5)
+        tr = _trainer(tmp_path, B, True, n=max(64, 4 * B))
+        tr.fusion.train(); tr.clf.train()
+        it = iter(tr.train_loader)
+        batches = [next(it) for _ in range(2)]
+        losses = []
+        for k in range(40):
+            out = tr.train_step(batches[k % 2])
+            losses.append(out["loss"].clone())
+        torch.cuda.synchronize()
+        res.append((torch.stack(losses), tr.arena.data.clone(), out["logits"].clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert bool(torch.isfinite(res[0][0]).all())
