@@ -43,7 +43,8 @@ constexpr int VEC_OFF = ST_OFF + BM * 8;                 // bias | colsum | gamm
 constexpr int GRD_OFF = VEC_OFF + 4 * BN * 4;            // the waves' guard maxima
 constexpr int SMEM = GRD_OFF + 64;
 constexpr int NK = 12;                                   // K-steps per tile (K = 768)
-constexpr int MIN_TILES = 512;                           // automatic choice: at least two tiles per workgroup
+constexpr int MIN_TILES = 512;                           // automatic choice: at least two tiles per workgroup (folded LayerNorm + activation)
+constexpr int MANY_TILES = 2048;                         // ... and every mode from eight tiles per workgroup on
 constexpr int NPATCH = 8;                                // 8-row x 64-column patches per wave tile: the patch of K-step s is patch s
 static_assert(SMEM <= 160 * 1024, "LDS budget");
 static_assert(NK % STA == 0 && NK % STB == 0, "a tile must start on slot 0 of both rings");
@@ -714,9 +715,15 @@ static int pp_stat_parts(int N) { return ((N / 32) % 2 == 0 && N / 32 <= 24) ? N
 // (FFN1: 16,384 x 3072 106 -> 101 us, 65,536 x 3072 436 -> 393 us, ViT 6,400 x 3072 46.1 -> 42.9 us) -- and a workgroup gets at
 // least two tiles; with a short epilogue (Q/K/V, the residual Linears) the 256 x 256 / 256 x 192 tiles' denser K loop wins
 // (66.7 vs 70.1 us, 36.7 vs 38.7 us), and at one and a half tiles per workgroup (4,096 rows) the tail does (30.6 vs 37.3 us).
+// With MANY tiles per workgroup the picture changes: the prologue and the one un-overlapped epilogue amortise, and every mode wins
+// (65,536 rows: Q/K/V 293 -> 268 us, the LayerNorm-residual out-projection 145 -> 114 us; profiles/r04_gemm_pp_bench.txt, last block):
+// from MANY_TILES on (eight per workgroup) every K = 768 call takes this form.
 static bool pp_pick(const GemmArgs& a) {
-  if (!pp_shape_ok(a.M, a.N, a.K) || pp_mode_of(a) != pp::FOLD || a.act == UFND_ACT_NONE) return false;
-  return (long long)(a.M / pp::BM) * (a.N / pp::BN) >= pp::MIN_TILES;
+  const int mode = pp_mode_of(a);
+  if (mode < 0 || !pp_shape_ok(a.M, a.N, a.K) || (mode != pp::FOLD && mode != pp::PLAIN && a.act != UFND_ACT_NONE)) return false;
+  const long long tiles = (long long)(a.M / pp::BM) * (a.N / pp::BN);
+  if (tiles >= pp::MANY_TILES) return true;
+  return mode == pp::FOLD && a.act != UFND_ACT_NONE && tiles >= pp::MIN_TILES;
 }
 
 }  // namespace
