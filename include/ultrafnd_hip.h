@@ -197,7 +197,7 @@ int ufnd_classifier_backward_ex(const ufnd_dims* d, const ufnd_clf_params* p, co
  *      contiguous pack of ufnd_head_factor_floats(d, B) floats (one launch; 2.5 MB at B = 32, hidden 512);
  *   3. all-gather the packs (rank r's pack at packs + r * rank_stride);
  *   4. ufnd_head_linear_grads_from_factors: the SUMMED dW / db of every Linear over ranks * B rows, written into the
- *      gradient tables in one grouped launch, two when (hidden + aux_dim) % 4 != 0 (fp32 MFMA; rows in rank order, so every rank computes the same bits).
+ *      gradient tables in one grouped launch -- two from 128 gathered rows on when (hidden + aux_dim) % 4 != 0 -- (fp32 MFMA; rows in rank order, so every rank computes the same bits).
  * The remaining gradients (gates, thresholds, leaves, bypass, evidence_proj: 21 k floats) are summed by an ordinary
  * all-reduce.  ranks == 1 reproduces the plain backward's dW / db bit for bit.
  * ---------------------------------------------------------------------------------- */

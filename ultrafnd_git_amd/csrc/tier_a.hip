@@ -1587,9 +1587,9 @@ extern "C" int ufnd_head_linear_grads_from_factors(const ufnd_dims* d, const ufn
   TnProb tn[UFND_GEMM_MAX_PROB];
   int n = fusion_tn_fuse(*d, f, fusion_grads, M, tn, sg);
   n += fusion_tn_rest(*d, f, fusion_grads, M, tn + n, sg);
-  // (the classifier's two problems stay a launch of their own, as in the backward: pre.0 is (hidden + aux) wide, which is not a
-  //  multiple of 4, and one such problem would put the whole grouped launch on 8-byte loads and stores)
-  const bool aux_vec4 = (d->hidden + d->aux_dim) % 4 == 0;
+  // (from 128 rows on -- the batch-split form of the kernel, one vector width per launch -- the classifier's two problems stay a launch
+  //  of their own: pre.0 is (hidden + aux) wide, not a multiple of 4, and would put the whole grouped launch on 8-byte accesses)
+  const bool aux_vec4 = (d->hidden + d->aux_dim) % 4 == 0 || M < 128;      // (below 128 rows the grouped kernel keeps a vector width per problem)
   if (aux_vec4) n += clf_tn(*d, c, clf_grads, M, tn + n, sg);
   TRY(launch_tn(tn, n, (hipStream_t)stream_));
   if (!aux_vec4) {
