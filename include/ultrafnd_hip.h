@@ -299,8 +299,8 @@ int ufnd_gemm_bf16(const void* A, const void* W, const float* bias, const float*
  * only (ufnd_gemm_bf16_ln: folded LayerNorm [+ activation], or the bf16 residual stream with out_stats; no fp32 residual /
  * output); any other call that names it is refused.  Same bits as the table's tiles (tests/test_gpu_gemm_pp.py).  The
  * automatic choice takes it for folded-LayerNorm calls with an activation once a workgroup gets two tiles (the FFN1 Linears
- * of both encoders at encoder lookahead >= 2), and for every supported call from 2,048 tiles on (eight per workgroup: the
- * configs[3] geometry, 65,536+ rows per launch). */
+ * of both encoders at encoder lookahead >= 2), and for every supported call with at least three tiles per workgroup whose
+ * last round of tiles is at least 93 % full (the configs[3] geometry, 65,536+ rows per launch). */
 #define UFND_GEMM_TILE_PERSISTENT 64
 int ufnd_gemm_bf16_ex(const void* A, const void* W, const float* bias, const float* residual, void* out_bf16,
                       float* out_f32, int M, int N, int K, int lda, int ldw, int ldr, int ldo, int ldf, int act,

@@ -26,6 +26,8 @@ SHAPES = {
     "out_res": (16384, 768, 768, "res", 0, 22), "qkv0": (16384, 2304, 768, "plain", 0, 22),
     "vit_ffn1": (6400, 3072, 768, "fold", 2, 22), "vit_qkv": (6400, 2304, 768, "fold", 0, 15), "vit_out": (6400, 768, 768, "res", 0, 17),
     "l512_ffn1": (65536, 3072, 768, "fold", 1, 15), "b32_ffn1": (4096, 3072, 768, "fold", 1, 22),
+    "m32k_qkv": (32768, 2304, 768, "fold", 0, 22), "m32k_out": (32768, 768, 768, "rln", 0, 22), "m32k_plain": (32768, 2304, 768, "plain", 0, 22),
+    "m24k_qkv": (24576, 2304, 768, "fold", 0, 22), "l512_res": (65536, 768, 768, "res", 0, 22),
     "l512_qkv": (65536, 2304, 768, "fold", 0, 22), "l512_out": (65536, 768, 768, "rln", 0, 22), "f8_ffn1": (12800, 3072, 768, "fold", 2, 22),
 }
 

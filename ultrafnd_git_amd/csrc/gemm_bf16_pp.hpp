@@ -44,7 +44,6 @@ constexpr int GRD_OFF = VEC_OFF + 4 * BN * 4;            // the waves' guard max
 constexpr int SMEM = GRD_OFF + 64;
 constexpr int NK = 12;                                   // K-steps per tile (K = 768)
 constexpr int MIN_TILES = 512;                           // automatic choice: at least two tiles per workgroup (folded LayerNorm + activation)
-constexpr int MANY_TILES = 2048;                         // ... and every mode from eight tiles per workgroup on
 constexpr int NPATCH = 8;                                // 8-row x 64-column patches per wave tile: the patch of K-step s is patch s
 static_assert(SMEM <= 160 * 1024, "LDS budget");
 static_assert(NK % STA == 0 && NK % STB == 0, "a tile must start on slot 0 of both rings");
@@ -715,15 +714,18 @@ static int pp_stat_parts(int N) { return ((N / 32) % 2 == 0 && N / 32 <= 24) ? N
 // (FFN1: 16,384 x 3072 106 -> 101 us, 65,536 x 3072 436 -> 393 us, ViT 6,400 x 3072 46.1 -> 42.9 us) -- and a workgroup gets at
 // least two tiles; with a short epilogue (Q/K/V, the residual Linears) the 256 x 256 / 256 x 192 tiles' denser K loop wins
 // (66.7 vs 70.1 us, 36.7 vs 38.7 us), and at one and a half tiles per workgroup (4,096 rows) the tail does (30.6 vs 37.3 us).
-// With MANY tiles per workgroup the picture changes: the prologue and the one un-overlapped epilogue amortise, and every mode wins
-// (65,536 rows: Q/K/V 293 -> 268 us, the LayerNorm-residual out-projection 145 -> 114 us; profiles/r04_gemm_pp_bench.txt, last block):
-// from MANY_TILES on (eight per workgroup) every K = 768 call takes this form.
+// With SEVERAL tiles per workgroup and an even split the picture changes: the prologue and the one un-overlapped epilogue amortise,
+// and every mode wins (profiles/r04_gemm_pp_bench.txt, last blocks): 65,536 rows Q/K/V 293 -> 268 us, LayerNorm-residual out-projection
+// 145 -> 114 us; 32,768 x 768 (exactly 3 tiles per workgroup) 66.6 -> 55.0 us; 24,576 x 2304 (6.75) 109.6 -> 97.1 us -- while 16,384 x 2304
+// (4.5 tiles per workgroup: a fifth round that is half empty) loses, 66.7 -> 70.1 us.  So: at least three tiles per workgroup AND at
+// least 93 % of the last round filled.
 static bool pp_pick(const GemmArgs& a) {
   const int mode = pp_mode_of(a);
   if (mode < 0 || !pp_shape_ok(a.M, a.N, a.K) || (mode != pp::FOLD && mode != pp::PLAIN && a.act != UFND_ACT_NONE)) return false;
   const long long tiles = (long long)(a.M / pp::BM) * (a.N / pp::BN);
-  if (tiles >= pp::MANY_TILES) return true;
-  return mode == pp::FOLD && a.act != UFND_ACT_NONE && tiles >= pp::MIN_TILES;
+  if (mode == pp::FOLD && a.act != UFND_ACT_NONE && tiles >= pp::MIN_TILES) return true;
+  const long long G = pp_cu_count() & ~7, rounds = (tiles + G - 1) / G;
+  return G > 0 && tiles >= 3 * G && tiles * 100 >= rounds * G * 93;
 }
 
 }  // namespace
