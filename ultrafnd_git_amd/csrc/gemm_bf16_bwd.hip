@@ -217,15 +217,20 @@ __global__ __launch_bounds__(256) void refresh_operands_kernel(const ufnd_refres
 }
 
 // A weight-gradient product has few output tiles and a long K (the tokens): the K range is cut into slices of at least eight
-// 64-token K-steps.  Tile: the largest one that still gives the chip a full round of workgroups with the slices available.
+// 64-token K-steps.  Tile: 128 x 128 first when it fills a round of workgroups with the slices available (round 4: with 256 x 256
+// tiles first an FFN gradient needed 8 slices -- nine passes over a 9.4 MB slab set per Linear -- where 128 x 128 needs 4: the step
+// 10.58-10.73 -> 10.18 ms on one box, A/B/A; 128 x 64 first: another 0.8 %, inside the noise), else the largest that does.
 int wgrad_cfg(int n_out, int k_in, int m_tokens) {
   const int smax = m_tokens / 64 / 8 > 1 ? m_tokens / 64 / 8 : 1;
-  const int cand[4] = {15, 22, 16, 20};              // 256x256, 256x192, 128x128, 128x64
-  for (int i = 0; i < 4; ++i) {
+#ifndef UFND_WGRAD_FIRST
+#define UFND_WGRAD_FIRST 16
+#endif
+  const int cand[5] = {UFND_WGRAD_FIRST, 15, 22, 16, 20};      // 256x256, 256x192, 128x128, 128x64 (experiments: --defs=UFND_WGRAD_FIRST=16 tries that tile first)
+  for (int i = 0; i < 5; ++i) {
     const TileCfg& t = kTiles[cand[i]];
     if (k_in % t.bn) continue;
     const long long tiles = (long long)ufnd_cdiv(n_out, t.bm) * (k_in / t.bn);
-    if (tiles * smax >= 256 || i == 3) return cand[i];
+    if (tiles * smax >= 256 || i == 4) return cand[i];
   }
   return 20;
 }
