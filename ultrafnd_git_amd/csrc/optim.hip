@@ -137,7 +137,23 @@ __global__ __launch_bounds__(256) void adamw_clip_kernel(float* p, const float* 
   f32x4* m4 = reinterpret_cast<f32x4*>(m);
   f32x4* v4 = reinterpret_cast<f32x4*>(v);
   const AdamScalars k{b1, b2, eps, decay, gs, step_size, inv_bc2};
-  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+#ifndef UFND_ADAMW_UNROLL
+#define UFND_ADAMW_UNROLL 2
+#endif
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+  if constexpr (UFND_ADAMW_UNROLL == 2) {      // two elements' loads in flight before the first store (the arrays alias nothing, but the compiler cannot know)
+    for (; i + stride < n4; i += 2 * stride) {
+      const size_t j = i + stride;
+      f32x4 pa = p4[i], ma = m4[i], va = v4[i], ga = g4[i];
+      f32x4 pb = p4[j], mb = m4[j], vb = v4[j], gb = g4[j];
+      adamw_vec(pa, ma, va, ga, k);
+      adamw_vec(pb, mb, vb, gb, k);
+      p4[i] = pa; m4[i] = ma; v4[i] = va;
+      p4[j] = pb; m4[j] = mb; v4[j] = vb;
+    }
+  }
+  for (; i < n4; i += stride) {
     f32x4 pp = p4[i], mm = m4[i], vv = v4[i];
     adamw_vec(pp, mm, vv, g4[i], k);
     p4[i] = pp; m4[i] = mm; v4[i] = vv;
