@@ -237,7 +237,10 @@ int wgrad_cfg(int n_out, int k_in, int m_tokens) {
 int wgrad_slices(int n_out, int k_in, int m_tokens, int cfg) {
   const long long tiles = (long long)ufnd_cdiv(n_out, kTiles[cfg].bm) * (k_in / kTiles[cfg].bn);
   const int nk = m_tokens / 64;
-  long long s = (512 + tiles - 1) / tiles;             // about two rounds of workgroups
+#ifndef UFND_WGRAD_BLOCKS
+#define UFND_WGRAD_BLOCKS 512
+#endif
+  long long s = (UFND_WGRAD_BLOCKS + tiles - 1) / tiles;             // about two rounds of workgroups
   if (s > nk / 8) s = nk / 8;
   if (s < 1) s = 1;
   const int per = (nk + (int)s - 1) / (int)s;          // every slice must own at least one K-step

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void nt_kernel(const NtArgs args) {
 
   // Batches of U 8-wide chunks: every load of a batch is issued before its first MFMA, so a wave
   // keeps U x (1 + MT) 16-B loads in flight (the loop is latency-bound, not bandwidth-bound).
-  constexpr int U = 4;
+  constexpr int U = 4;      // (8 chunks per batch measured in round 4: no change, 0.2337 vs 0.2334 ms per head step)
   int k = k0;
   for (; k + 8 * U <= k1; k += 8 * U) {
     float a[U][4], b[U][MT][4];

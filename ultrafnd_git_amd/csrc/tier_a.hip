@@ -14,8 +14,14 @@
 namespace {
 
 constexpr uint32_t LAYER_FUSE0 = 1, LAYER_FUSE3 = 2, LAYER_PRE0 = 3, LAYER_PRE3 = 4, LAYER_TREE = 5;
-constexpr int KSPLIT_FUSE0 = 16;  // fuse_mlp.0 forward: K = 16H split 16 ways (x4 waves in-block)
-constexpr int NSPLIT_FUSE0 = 4;   // fuse_mlp.0 dX: contraction 2H split 4 ways (x4 waves in-block)
+#ifndef UFND_NSPLIT_FUSE0
+#define UFND_NSPLIT_FUSE0 4
+#endif
+// fuse_mlp.0 forward: K = 16H split over the grid (x4 waves in-block), then one epilogue pass over the partials.  Measured (round 4, one
+// box, A/B/A; 16 ways before): B = 32: 8 ways 0.2309 ms per head step against 0.2347-0.2357 (16), 0.2354 (4), 0.2364 (12); B = 256: 0.5146
+// (8) against 0.5176-0.5188 (16) and 0.5016 (4).  One value for every batch size: a row's arithmetic does not depend on its batch.
+constexpr int KSPLIT_FUSE0 = 8;
+constexpr int NSPLIT_FUSE0 = UFND_NSPLIT_FUSE0;  // fuse_mlp.0 dX: contraction 2H split 4 ways (x4 waves in-block)
 
 inline size_t al64(size_t n) { return (n + 63) & ~(size_t)63; }
 
