@@ -630,9 +630,15 @@ typedef struct ufnd_partials_job {
  *   2. the NT kernel over the token dimension in slices (slab_workspace: ufnd_gemm_bf16_wgrad_workspace_floats(N, K, Mpad));
  *   3. ONE finish launch: slab reduce of dW, column-sum finish of db (colsum_workspace: ufnd_transpose_colsum_workspace_floats)
  *      and, if `extra` != NULL, a deferred LayerNorm dgamma / dbeta finish.
- * Same arithmetic in the same order as the five-launch sequence: bit-identical gradients. */
+ * Same arithmetic in the same order as the five-launch sequence: bit-identical gradients.
+ * `part`: UFND_WGRAD_ALL, or the two halves for a caller that runs the product beside its data-gradient chain on a second
+ * stream: UFND_WGRAD_TRANSPOSE (launch 1: dY and X are free to be overwritten once it has run), then UFND_WGRAD_PRODUCT
+ * (launches 2 and 3, same arguments). */
+#define UFND_WGRAD_ALL 0
+#define UFND_WGRAD_TRANSPOSE 1
+#define UFND_WGRAD_PRODUCT 2
 int ufnd_linear_wgrad(const void* dY, int lddy, const void* X, int ldx, int M, int N, int K, float* dW, float* db, void* dYt, void* Xt, int ldt,
-                      float* slab_workspace, float* colsum_workspace, const ufnd_partials_job* extra, void* stream);
+                      float* slab_workspace, float* colsum_workspace, const ufnd_partials_job* extra, int part, void* stream);
 
 /* bf16 W (rows, ld_w) and W^T (cols, ld_wt) of MANY Linears from their fp32 masters (rows, ld_master) in ONE launch (after an
  * optimizer step).  rows and cols multiples of 64, every pointer 16-B aligned, ld_master % 4 == 0, ld_w % 8 == 0, ld_wt % 8 == 0;

@@ -69,6 +69,13 @@ def test_text_encoder_gradients_vs_oracle_autograd(tag):
     bp.forward_train(ids, mask)
     bp.backward(torch.randn(ref_feat.shape, generator=torch.Generator().manual_seed(meta["loss_seed"])).to(DEV))
     assert torch.equal(torch.nan_to_num(arena.grad, nan=-7.0), torch.nan_to_num(first, nan=-7.0))      # no atomics: identical bits (padding stays NaN)
+    # the weight-gradient products on a second stream beside the data-gradient chain (double-buffered operand copies, events): same bits
+    bp.overlap_wgrad = True
+    arena.grad.fill_(float("nan"))
+    bp.forward_train(ids, mask)
+    bp.backward(torch.randn(ref_feat.shape, generator=torch.Generator().manual_seed(meta["loss_seed"])).to(DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(torch.nan_to_num(arena.grad, nan=-7.0), torch.nan_to_num(first, nan=-7.0))
 
 
 @pytest.mark.parametrize("tag", ["vit2_F1", "vit2_F2"])

@@ -81,6 +81,7 @@ class RefreshItem(C.Structure):
 
 
 PARTIALS_DEFER = 2
+WGRAD_ALL, WGRAD_TRANSPOSE, WGRAD_PRODUCT = 0, 1, 2
 
 
 class GemmLn(C.Structure):
@@ -185,7 +186,7 @@ def _declare_encoders(lib: C.CDLL) -> None:
         "ufnd_gemm_bf16_dgrad": [P] * 6 + [I] * 10 + [P],
         "ufnd_gemm_bf16_wgrad": [P, P, P, I, I, I, I, I, I, P, I, P],
         "ufnd_transpose_bf16": [P, I, I, I, I, P, I, I, P, P, I, P],
-        "ufnd_linear_wgrad": [P, I, P, I, I, I, I, P, P, P, P, I, P, P, C.POINTER(PartialsJob), P],
+        "ufnd_linear_wgrad": [P, I, P, I, I, I, I, P, P, P, P, I, P, P, C.POINTER(PartialsJob), I, P],
         "ufnd_refresh_operands": [P, I, I, P],
         "ufnd_layernorm_bwd_blocks": [I],
         "ufnd_row_partials_finish": [C.POINTER(PartialsJob), I, P],

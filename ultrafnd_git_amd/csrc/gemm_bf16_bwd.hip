@@ -308,7 +308,8 @@ extern "C" int ufnd_gemm_bf16_wgrad(const void* dYt, const void* Xt, float* dW, 
 }
 
 extern "C" int ufnd_linear_wgrad(const void* dY, int lddy, const void* X, int ldx, int M, int N, int K, float* dW, float* db, void* dYt, void* Xt, int ldt,
-                                 float* slab_workspace, float* colsum_workspace, const ufnd_partials_job* extra, void* stream_) {
+                                 float* slab_workspace, float* colsum_workspace, const ufnd_partials_job* extra, int part, void* stream_) {
+  UFND_REQUIRE(part == UFND_WGRAD_ALL || part == UFND_WGRAD_TRANSPOSE || part == UFND_WGRAD_PRODUCT, "linear_wgrad: part=%d", part);
   UFND_REQUIRE(dY && X && dW && dYt && Xt && slab_workspace, "linear_wgrad: null operand");
   UFND_REQUIRE(M >= 1 && N >= 8 && N % 8 == 0 && K >= 64 && K % 64 == 0, "linear_wgrad: M=%d N=%d K=%d (N %% 8 == 0, K %% 64 == 0)", M, N, K);
   const int Mp = (M + 63) / 64 * 64;
@@ -319,9 +320,12 @@ extern "C" int ufnd_linear_wgrad(const void* dY, int lddy, const void* X, int ld
   UFND_REQUIRE(!extra || (extra->part && extra->nblk >= 1 && extra->H >= 16 && (extra->out0 || extra->out1)), "linear_wgrad: extra finish job");
   hipStream_t stream = (hipStream_t)stream_;
   const int wide = N > K ? N : K, row_tiles = Mp / 64;
-  hipLaunchKernelGGL(transpose_pair_kernel, dim3(ufnd_cdiv(wide, 64), row_tiles, 2), dim3(256), 0, stream, (const __bf16*)dY, lddy, N, (const __bf16*)X, ldx, K, M,
-                     (__bf16*)dYt, (__bf16*)Xt, ldt, Mp, db ? colsum_workspace : (float*)nullptr);
-  UFND_CHECK_LAUNCH();
+  if (part != UFND_WGRAD_PRODUCT) {
+    hipLaunchKernelGGL(transpose_pair_kernel, dim3(ufnd_cdiv(wide, 64), row_tiles, 2), dim3(256), 0, stream, (const __bf16*)dY, lddy, N, (const __bf16*)X, ldx, K, M,
+                       (__bf16*)dYt, (__bf16*)Xt, ldt, Mp, db ? colsum_workspace : (float*)nullptr);
+    UFND_CHECK_LAUNCH();
+    if (part == UFND_WGRAD_TRANSPOSE) return UFND_OK;
+  }
   const int cfg = wgrad_cfg(N, K, Mp);
   UFND_REQUIRE(K % kTiles[cfg].bn == 0, "linear_wgrad: tile %d needs K %% %d == 0", cfg, kTiles[cfg].bn);
   const int S = wgrad_slices(N, K, Mp, cfg);

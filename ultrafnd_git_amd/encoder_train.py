@@ -47,7 +47,12 @@ class _Backprop:
         self._scratch: Dict[Tuple, dict] = {}
         self.saved: Optional[dict] = None
         self._refresh = None               # (device table, items, tiles, names left to the per-Linear path) of the grouped operand refresh
-        self._pending_ln = None            # a LayerNorm backward's deferred dgamma / dbeta finish (rides in the next Linear's finish launch)
+        self._pending_ln = None            # (job, scratch, buffer index) of a LayerNorm backward's deferred dgamma / dbeta finish (rides in the next Linear's finish launch)
+        self._wg_side = None               # the stream of the weight-gradient products
+        self._wg_open = False
+        # weight-gradient products on a second stream beside the data-gradient chain.  Off: measured A/B/A/B on one box, 9.56 / 9.12 ms with it against
+        # 9.32 / 9.19 without -- the event traffic takes the host enqueue from 6.4 to 8.7-9.3 ms per step, which is the step time (the step turns host-bound)
+        self.overlap_wgrad = False
 
     # ------------------------------------------------------------------ parameters
     def groups(self) -> List[List[Tuple[str, Tuple[int, ...]]]]:
@@ -142,11 +147,15 @@ class _Backprop:
             dev, Mp, wmax = self.enc.device, _pad64(M), max(widths)
             lib = L.lib()
             ws = max(lib.ufnd_gemm_bf16_wgrad_workspace_floats(a, b, Mp) for a in widths for b in widths if b % 64 == 0)
+            two = lambda make: [make(), make()]
+            # two buffer sets: the weight-gradient product of one Linear runs on a second stream while the main stream transposes the next
+            # Linear's operands into the other set (busy[k] / ln_busy[k]: the event after which set k may be rewritten)
             self._scratch[key] = {
-                "t1": torch.zeros(wmax, Mp, dtype=torch.bfloat16, device=dev), "t2": torch.zeros(wmax, Mp, dtype=torch.bfloat16, device=dev),
-                "wg": torch.empty(max(1, ws), dtype=torch.float32, device=dev),
-                "cs": torch.empty(lib.ufnd_transpose_colsum_workspace_floats(Mp, wmax), dtype=torch.float32, device=dev),
-                "ln": torch.empty(lib.ufnd_layernorm_bwd_workspace_floats(M, self.enc.hidden), dtype=torch.float32, device=dev)}
+                "t1": two(lambda: torch.zeros(wmax, Mp, dtype=torch.bfloat16, device=dev)), "t2": two(lambda: torch.zeros(wmax, Mp, dtype=torch.bfloat16, device=dev)),
+                "wg": two(lambda: torch.empty(max(1, ws), dtype=torch.float32, device=dev)),
+                "cs": two(lambda: torch.empty(lib.ufnd_transpose_colsum_workspace_floats(Mp, wmax), dtype=torch.float32, device=dev)),
+                "ln": two(lambda: torch.empty(lib.ufnd_layernorm_bwd_workspace_floats(M, self.enc.hidden), dtype=torch.float32, device=dev)),
+                "flip": 0, "busy": [None, None], "ln_flip": 0, "ln_busy": [None, None]}
         return self._scratch[key]
 
     # ------------------------------------------------------------------ building blocks
@@ -164,34 +173,73 @@ class _Backprop:
 
     def _wgrad(self, sc: dict, dy, x, dW: torch.Tensor, db: Optional[torch.Tensor]) -> None:
         """dW (N, K) = dy (M, N)^T x (M, K); db (N) = column sums of dy.  (Overwrites: every step writes every gradient.)  Three
-        launches (ufnd_linear_wgrad): both transposes, the sliced NT product, one finish pass -- which also carries a pending
-        LayerNorm's dgamma / dbeta finish."""
+        launches (ufnd_linear_wgrad): both transposes on the caller's stream -- dy may be overwritten behind them -- then the sliced NT
+        product and one finish pass (which also carries a pending LayerNorm's dgamma / dbeta finish) on a SECOND stream, beside the
+        data-gradient chain that continues on the caller's: the weight gradients are not on backward's critical path.  join_wgrad() ends it."""
         import ctypes as C
         M, N = dy.shape
         K = x.shape[1]
-        t1, t2 = sc["t1"], sc["t2"]
+        lib, dev = L.lib(), dy.device
+        main = torch.cuda.current_stream(dev)
+        if not self.overlap_wgrad:         # everything on the caller's stream (one buffer set)
+            job, self._pending_ln = self._pending_ln, None
+            L.check(lib.ufnd_linear_wgrad(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), M, N, K, dW.reshape(N, -1).data_ptr(), L.ptr(db),
+                                          sc["t1"][0].data_ptr(), sc["t2"][0].data_ptr(), sc["t1"][0].stride(0), sc["wg"][0].data_ptr(), sc["cs"][0].data_ptr(),
+                                          C.byref(job[0]) if job is not None else None, L.WGRAD_ALL, main.cuda_stream), "ufnd_linear_wgrad")
+            return
+        if self._wg_side is None:
+            self._wg_side = torch.cuda.Stream(device=dev)
+        side = self._wg_side
+        k = sc["flip"]
+        sc["flip"] ^= 1
+        if sc["busy"][k] is not None:
+            main.wait_event(sc["busy"][k])             # the product that read this buffer set last
+        t1, t2 = sc["t1"][k], sc["t2"][k]
         dW2 = dW.reshape(N, -1)
         job, self._pending_ln = self._pending_ln, None
-        L.check(L.lib().ufnd_linear_wgrad(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), M, N, K, dW2.data_ptr(), L.ptr(db), t1.data_ptr(),
-                                          t2.data_ptr(), t1.stride(0), sc["wg"].data_ptr(), sc["cs"].data_ptr(), C.byref(job) if job is not None else None,
-                                          L.stream_ptr(dy.device)), "ufnd_linear_wgrad")
+        args = (dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), M, N, K, dW2.data_ptr(), L.ptr(db), t1.data_ptr(), t2.data_ptr(), t1.stride(0),
+                sc["wg"][k].data_ptr(), sc["cs"][k].data_ptr(), C.byref(job[0]) if job is not None else None)
+        L.check(lib.ufnd_linear_wgrad(*args, L.WGRAD_TRANSPOSE, main.cuda_stream), "ufnd_linear_wgrad")
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        L.check(lib.ufnd_linear_wgrad(*args, L.WGRAD_PRODUCT, side.cuda_stream), "ufnd_linear_wgrad")
+        done = torch.cuda.Event()
+        done.record(side)
+        sc["busy"][k] = done
+        if job is not None:
+            job[1]["ln_busy"][job[2]] = done            # the LayerNorm partials it finished may be overwritten after this
+        self._wg_open = True
+
+    def join_wgrad(self) -> None:
+        """The caller's stream waits for every weight-gradient product started so far (end of a backward)."""
+        if self._wg_open:
+            torch.cuda.current_stream(self.enc.device).wait_stream(self._wg_side)
+            self._wg_open = False
 
     def _flush_ln(self) -> None:
         """A deferred LayerNorm finish that no Linear picked up (the next kernel is another LayerNorm backward, or the backward ends)."""
         import ctypes as C
         if self._pending_ln is not None:
             job, self._pending_ln = self._pending_ln, None
-            L.check(L.lib().ufnd_row_partials_finish(C.byref(job), 0, L.stream_ptr(self.enc.device)), "ufnd_row_partials_finish")
+            L.check(L.lib().ufnd_row_partials_finish(C.byref(job[0]), 0, L.stream_ptr(self.enc.device)), "ufnd_row_partials_finish")
+            job[1]["ln_busy"][job[2]] = None            # (stream order protects the buffer)
 
     def _ln_bwd(self, sc: dict, x, ldx, gamma, dy, dx_f32, dx_bf16, lddx, dgamma, dbeta, M, add=None):
         H = self.enc.hidden
-        self._flush_ln()                   # (the workspace below may be the pending job's)
+        self._flush_ln()                   # one pending job at a time: a LayerNorm backward right behind another one finishes the first here
+        kk = sc["ln_flip"]
+        sc["ln_flip"] ^= 1
+        if sc["ln_busy"][kk] is not None:  # the finish (on the weight-gradient stream) that read this workspace last
+            torch.cuda.current_stream(x.device).wait_event(sc["ln_busy"][kk])
+            sc["ln_busy"][kk] = None
+        ws = sc["ln"][kk]
         L.check(L.lib().ufnd_layernorm_bwd(x.data_ptr(), ldx, gamma.data_ptr(), dy.data_ptr(), dy.stride(0), L.ptr(add), add.stride(0) if add is not None else 0,
-                                           L.ptr(dx_f32), L.ptr(dx_bf16), lddx, L.ptr(dgamma), L.ptr(dbeta), sc["ln"].data_ptr(), L.PARTIALS_DEFER, M, H,
+                                           L.ptr(dx_f32), L.ptr(dx_bf16), lddx, L.ptr(dgamma), L.ptr(dbeta), ws.data_ptr(), L.PARTIALS_DEFER, M, H,
                                            self.enc.eps, L.stream_ptr(x.device)), "ufnd_layernorm_bwd")
         job = L.PartialsJob()
-        job.part, job.nblk, job.H, job.out0, job.out1 = sc["ln"].data_ptr(), L.lib().ufnd_layernorm_bwd_blocks(M), H, dgamma.data_ptr(), dbeta.data_ptr()
-        self._pending_ln = job
+        job.part, job.nblk, job.H, job.out0, job.out1 = ws.data_ptr(), L.lib().ufnd_layernorm_bwd_blocks(M), H, dgamma.data_ptr(), dbeta.data_ptr()
+        self._pending_ln = (job, sc, kk)
 
     def _attn_bwd(self, qkv, ctx, dctx, lse, mask, dqkv, ws, B, Lq):
         L.check(L.lib().ufnd_attention_bf16_bwd(qkv.data_ptr(), ctx.data_ptr(), dctx.data_ptr(), lse.data_ptr(), L.ptr(mask), dqkv.data_ptr(), ws.data_ptr(),
@@ -326,6 +374,7 @@ class TextBackprop(_Backprop):
                                             self.grad([ek + "position_embeddings.weight"]).data_ptr(), self.grad([ek + "token_type_embeddings.weight"]).data_ptr(),
                                             B, Lq, H, e.vocab, e.max_position, self.master([ek + "token_type_embeddings.weight"]).shape[0], s), "ufnd_bert_embed_bwd")
         self._flush_ln()                   # (the embedding LayerNorm's dgamma / dbeta: no Linear follows it)
+        self.join_wgrad()
 
 
 # =============================================================================================
@@ -472,3 +521,4 @@ class VisualBackprop(_Backprop):
                 "ufnd_vit_assemble_bwd")
         self._wgrad(scp, sv["dpe"], sv["patches"], self.grad([V + "embeddings.patch_embedding.weight"]), None)
         self._flush_ln()
+        self.join_wgrad()
