@@ -55,7 +55,7 @@ def test_train_config_mirrors_the_reference_dataclass(parity):
     assert mine[:len(ref)] == ref                 # same fields, order and defaults; additions only at the end
     assert [n for n, _ in mine[len(ref):]] == ["device", "use_graph", "encode_inline", "label_smoothing", "class_weighting", "use_cosine",
                                                "min_lr_scale", "cu_split", "gnn_in_graph", "encoder_lookahead", "head_graph", "persistent_inputs",
-                                               "grad_payload", "grad_exchange", "train_encoders"]
+                                               "grad_payload", "grad_exchange", "train_encoders", "fused_head"]
 
 
 def test_arena_layout_keeps_stacked_groups_contiguous_and_aligned():

@@ -84,7 +84,6 @@ class TrainConfig:
     encoder_lookahead: int = 4
     # experiments / diagnostics that used to be environment variables
     head_graph: bool = True        # False: the head's forward / backward eagerly (dW kernels on a side stream) even with use_graph
-    fused_head: bool = True        # the head's forward + CE and its backward as two C-ABI calls (22 launches, same bits); False: the five module-level calls (26)
     # the loader rotates a small fixed set of device input buffers (bench.py: four): encoder graphs read them in place, one graph
     # per buffer set (pipeline.py).  False: every batch that is not one of the trainer's own group buffers is staged.
     persistent_inputs: bool = False
@@ -95,6 +94,8 @@ class TrainConfig:
     # fine-tune the encoders with the head (encoder_train.py: forward with saved activations + hand-written backward; needs
     # encode_inline and both encoders).  The reference keeps them frozen (text_blocks.py:52,63): False reproduces it.
     train_encoders: bool = False
+    # the head's forward + CE and its backward as two C-ABI calls over both modules (21 launches, same bits); False: the five module-level calls (26)
+    fused_head: bool = True
 
 
 class ForensicTrainer:
