@@ -210,7 +210,7 @@ def bench_train_encoders(args, dev, world, rank):
                       encode_inline=True, seed=42, train_encoders=True)
     tsync = TemporalSyncNet(in_dim=768, out_dim=256).to(dev)
     tr = ForensicTrainer(cfg, cache=synthetic_cache(64, seed=1), text_encoder=tenc, visual_encoder=venc, temporal_net=tsync)
-    tr.text_bp.overlap_wgrad = tr.vis_bp.overlap_wgrad = bool(args.wgrad_overlap)
+    tr.text_bp.overlap_wgrad = tr.vis_bp.overlap_wgrad = not args.no_wgrad_overlap
     tr.fusion.train(); tr.clf.train()
     batches = make_batches(B, 4, 42 + 2 + 1000 * rank, dev)
 
@@ -334,7 +334,7 @@ def main():
     ap.add_argument("--grad-exchange", choices=("all_reduce", "rs_ag", "factors"), default="all_reduce",
                     help="data-parallel exchange of the head's gradients (dp.py): bucketed all-reduce (default), reduce-scatter + all-gather, or "
                          "all-gathered factor panels with the Linear gradients formed locally over all ranks' rows")
-    ap.add_argument("--wgrad-overlap", action="store_true", help="--train-encoders: weight-gradient products on a second stream beside the data-gradient chain (experiment)")
+    ap.add_argument("--no-wgrad-overlap", action="store_true", help="--train-encoders: weight-gradient products on the backward's own stream instead of a second one")
     ap.add_argument("--train-encoders", action="store_true",
                     help="secondary measurement: fine-tune both encoders with the head (forward with saved activations + hand-written "
                          "backward; the reference keeps its encoders frozen)")

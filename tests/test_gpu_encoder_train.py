@@ -69,8 +69,9 @@ def test_text_encoder_gradients_vs_oracle_autograd(tag):
     bp.forward_train(ids, mask)
     bp.backward(torch.randn(ref_feat.shape, generator=torch.Generator().manual_seed(meta["loss_seed"])).to(DEV))
     assert torch.equal(torch.nan_to_num(arena.grad, nan=-7.0), torch.nan_to_num(first, nan=-7.0))      # no atomics: identical bits (padding stays NaN)
-    # the weight-gradient products on a second stream beside the data-gradient chain (double-buffered operand copies, events): same bits
-    bp.overlap_wgrad = True
+    # the weight-gradient products on the backward's own stream instead of the second one (the default: double-buffered operand copies, events): same bits
+    assert bp.overlap_wgrad
+    bp.overlap_wgrad = False
     arena.grad.fill_(float("nan"))
     bp.forward_train(ids, mask)
     bp.backward(torch.randn(ref_feat.shape, generator=torch.Generator().manual_seed(meta["loss_seed"])).to(DEV))

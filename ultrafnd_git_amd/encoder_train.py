@@ -47,12 +47,15 @@ class _Backprop:
         self._scratch: Dict[Tuple, dict] = {}
         self.saved: Optional[dict] = None
         self._refresh = None               # (device table, items, tiles, names left to the per-Linear path) of the grouped operand refresh
+        self._views: Dict[Tuple, torch.Tensor] = {}
+        self._lk_cache: Dict[int, dict] = {}
         self._pending_ln = None            # (job, scratch, buffer index) of a LayerNorm backward's deferred dgamma / dbeta finish (rides in the next Linear's finish launch)
         self._wg_side = None               # the stream of the weight-gradient products
         self._wg_open = False
-        # weight-gradient products on a second stream beside the data-gradient chain.  Off: measured A/B/A/B on one box, 9.56 / 9.12 ms with it against
-        # 9.32 / 9.19 without -- the event traffic takes the host enqueue from 6.4 to 8.7-9.3 ms per step, which is the step time (the step turns host-bound)
-        self.overlap_wgrad = False
+        # weight-gradient products on a second stream beside the data-gradient chain (they are not on backward's critical path).  Measured
+        # A/B/A/B on one box: 9.17 / 9.24 ms per step with it, 9.48 / 9.42 without -- once the host enqueue had come down to 4.6-5.2 ms per step
+        # (memoised arena views); at 6.4 ms the events' extra 2-3 ms of host time made the step host-bound and the overlap invisible
+        self.overlap_wgrad = True
 
     # ------------------------------------------------------------------ parameters
     def groups(self) -> List[List[Tuple[str, Tuple[int, ...]]]]:
@@ -75,9 +78,18 @@ class _Backprop:
         self.enc.weights_version += 1
         self._ops.clear()
         self._refresh = None
+        self._views.clear()
 
     def _stacked(self, buf: torch.Tensor, keys: List[str]) -> torch.Tensor:
-        """View of adjacent arena tensors as one matrix (q/k/v -> (3H, H)) or vector."""
+        """View of adjacent arena tensors as one matrix (q/k/v -> (3H, H)) or vector.  Memoised per buffer: a backward asks for ~400 of
+        them, and building a view costs more host time than enqueueing the kernel that uses it."""
+        ck = (buf.data_ptr(), keys[0], len(keys))
+        v = self._views.get(ck)
+        if v is None:
+            v = self._views[ck] = self._stacked_view(buf, keys)
+        return v
+
+    def _stacked_view(self, buf: torch.Tensor, keys: List[str]) -> torch.Tensor:
         o0, s0 = self.arena.offsets[self.prefix + keys[0]]
         n = 0
         for k in keys:
@@ -91,6 +103,13 @@ class _Backprop:
         rows = sum(self.arena.offsets[self.prefix + k][1][0] for k in keys)
         rest = tuple(s0[1:])
         return buf[o0:o0 + n].view((rows,) + rest)
+
+    def _lk(self, i: int) -> dict:
+        """The parameter names of layer i (built once: a dozen formatted strings per layer per pass otherwise)."""
+        k = self._lk_cache.get(i)
+        if k is None:
+            k = self._lk_cache[i] = self._lk_build(i)
+        return k
 
     def master(self, keys: List[str]) -> torch.Tensor:
         return self._stacked(self.arena.data, keys)
@@ -255,7 +274,7 @@ def _act(x: torch.Tensor, out: torch.Tensor, act: int) -> None:
 class TextBackprop(_Backprop):
     """BertTextEncoder with a backward: BertModel (post-LN) -> masked mean-pool -> L2."""
 
-    def _lk(self, i: int) -> dict:
+    def _lk_build(self, i: int) -> dict:
         P = f"encoder.layer.{i}."
         return {"qkv_w": [P + f"attention.self.{n}.weight" for n in ("query", "key", "value")],
                 "qkv_b": [P + f"attention.self.{n}.bias" for n in ("query", "key", "value")],
@@ -383,7 +402,7 @@ class VisualBackprop(_Backprop):
 
     V = "vision_model."
 
-    def _lk(self, i: int) -> dict:
+    def _lk_build(self, i: int) -> dict:
         P = self.V + f"encoder.layers.{i}."
         return {"qkv_w": [P + f"self_attn.{n}.weight" for n in ("q_proj", "k_proj", "v_proj")],
                 "qkv_b": [P + f"self_attn.{n}.bias" for n in ("q_proj", "k_proj", "v_proj")],
