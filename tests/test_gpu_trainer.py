@@ -376,3 +376,44 @@ def test_forty_steps_twice_leave_the_same_bits(tmp_path, B):
     for a, b in zip(*res):
         assert torch.equal(a, b)
     assert bool(torch.isfinite(res[0][0]).all())
+
+
+@pytest.mark.parametrize("hidden,B", [(256, 32), (1024, 16), (1024, 96)])
+def test_two_call_head_step_at_other_hidden_widths(tmp_path, hidden, B):
+    """The two-call head step against the five-call sequence at the other widths the kernels are built for (256: one 256-column chunk per row
+    kernel, 1024: four), through HeadStep on modules built from YAMLs of that width: logits, probabilities, forensic scalars, loss and the
+    whole gradient arena bit-identical (dropout on)."""
+    from types import SimpleNamespace
+    from ultrafnd_git_amd.arena import rehome
+    from ultrafnd_git_amd.classifier import DeepTruthClassifier
+    from ultrafnd_git_amd.dp import GradReducer
+    from ultrafnd_git_amd.fusion import CrossModalTransformer
+    from ultrafnd_git_amd.head_step import HeadStep
+    from ultrafnd_git_amd.optim import FusedAdamW
+    fy, cy = tmp_path / "fusion.yaml", tmp_path / "classifier.yaml"
+    fy.write_text(f"hidden_dim: {hidden}\ndropout: 0.1\nuse_gnn: true\ngnn_dim: 128\n")
+    cy.write_text(f"input_dim: {hidden}\nhidden_dim: {hidden}\ndropout: 0.1\nnum_classes: 2\nuse_aux: true\naux_dim: 2\nnode_trees: 6\nnode_depth: 4\n"
+                  "node_tau: 10.0\ntemperature: 1.0\n")
+    res = []
+    for fused in (True, False):
+        torch.manual_seed(11)
+        fusion, clf = CrossModalTransformer(str(fy)).to(DEV), DeepTruthClassifier(str(cy)).to(DEV)
+        arena = rehome([clf, fusion], ["clf.", "fusion."])
+        optim = FusedAdamW(arena, seed=7)
+        cfg = SimpleNamespace(use_graph=False, head_graph=False, label_smoothing=0.0, class_weighting=False, fused_head=fused)
+        hs = HeadStep(cfg, torch.device(DEV), fusion, clf, optim, GradReducer(arena.ensure_grad()))
+        assert hs.fused_entries == fused
+        fusion.train(); clf.train()
+        b = hs.bufs(B, True)
+        g = torch.Generator().manual_seed(3)
+        for k, d in (("text", 768), ("audio", 128), ("visual", 512), ("temporal", 256), ("gnn", 128)):
+            b[k].copy_(torch.randn(B, d, generator=g))
+        b["aux"].copy_(torch.rand(B, 2, generator=g))
+        b["label"].copy_(torch.randint(0, 2, (B,), generator=g))
+        arena.grad.fill_(float("nan"))
+        hs.fwd_bwd(b, B)
+        torch.cuda.synchronize()
+        res.append((b["logits"].clone(), b["probs"].clone(), b["forensic"].clone(), optim.state.float_view("loss").clone(), arena.grad.clone()))
+    for a, r in zip(*res):
+        assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(r, nan=-7.0))
+    assert bool(torch.isfinite(res[0][0]).all()) and float(res[0][4][torch.isfinite(res[0][4])].abs().sum()) > 0
